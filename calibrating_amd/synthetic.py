@@ -1,0 +1,85 @@
+"""Deterministic synthetic inputs: rectified stereo pairs and a test rig.
+
+NumPy only; used by bench.py, the tests and ``__graft_entry__.smoke()``.  No reference data set is
+reachable offline (calibrating/utils.py:722-739 clones it from the network), so every config of
+BASELINE.json is driven on these.
+"""
+import numpy as np
+
+
+def _box3(img):
+    """3x3 box mean (integer floor) with replicated border; img (H, W, cn) uint8."""
+    p = np.pad(img.astype(np.int32), ((1, 1), (1, 1), (0, 0)), mode="edge")
+    h, w = img.shape[:2]
+    s = np.zeros(img.shape, np.int32)
+    for dy in range(3):
+        for dx in range(3):
+            s += p[dy:dy + h, dx:dx + w]
+    return (s // 9).astype(np.uint8)
+
+
+def rectified_pair(seed=1234, H=1080, W=1920, D=128, cn=1):
+    """Appendix C.1: random texture, smooth sinusoidal ground-truth disparity in [D/8, 7D/8].
+
+    Returns (left, right) uint8 of shape (H, W) for cn == 1, (H, W, cn) otherwise.
+    """
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (H, W + D, cn), dtype=np.uint8)
+    base = _box3(base)
+    left = base[:, D:].copy()
+    yy, xx = np.mgrid[:H, :W]
+    g = np.rint(D / 8 + (3 * D / 4) * (0.5 + 0.5 * np.sin(2 * np.pi * xx / W) * np.cos(2 * np.pi * yy / H)))
+    g = g.astype(np.int64)
+    right = rng.integers(0, 256, (H, W, cn), dtype=np.uint8)  # holes
+    # ascending disparity order: nearer (larger g) written last, so it wins
+    xr = xx - g
+    order = np.argsort(g, axis=1, kind="stable")
+    rows = np.arange(H)[:, None]
+    xs_sorted = np.take_along_axis(xx, order, axis=1)
+    xr_sorted = np.take_along_axis(xr, order, axis=1)
+    ok = xr_sorted >= 0
+    # sequential semantics per row: later writes override earlier ones -> process in sorted order
+    # numpy fancy assignment keeps the last write for repeated indices when done column by column
+    for j in range(W):
+        m = ok[:, j]
+        r = rows[m, 0]
+        right[r, xr_sorted[m, j]] = left[r, xs_sorted[m, j]]
+    noise = rng.integers(-2, 3, right.shape)
+    right = np.clip(right.astype(np.int64) + noise, 0, 255).astype(np.uint8)
+    if cn == 1:
+        return left[..., 0], right[..., 0]
+    return left, right
+
+
+def rodrigues(r):
+    """cv2.Rodrigues(vector) -> 3x3."""
+    r = np.asarray(r, np.float64).reshape(3)
+    theta = np.linalg.norm(r)
+    if theta < np.finfo(np.float64).eps:
+        return np.eye(3)
+    k = r / theta
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(theta) * np.eye(3) + (1 - np.cos(theta)) * np.outer(k, k) + np.sin(theta) * K
+
+
+def rig(W=1280, H=720):
+    """Appendix C.2 rig as the dict ``Stereo.load`` accepts (stereo_camera.py:264-297)."""
+    K1 = [[0.8 * W, 0, W / 2 + 3.3], [0, 0.8 * W, H / 2 - 2.1], [0, 0, 1]]
+    K2 = [[0.8 * W * 1.01, 0, W / 2 + 3.3 - 4.7], [0, 0.8 * W * 1.01, H / 2 - 2.1], [0, 0, 1]]
+    return dict(
+        R=rodrigues([0.01, -0.02, 0.005]).tolist(),
+        t=[[-0.12], [0.002], [-0.001]],
+        cam1=dict(K=K1, D=[[-0.12, 0.05, 1e-3, -5e-4, 0.01]], xy=[W, H], name="cam1"),
+        cam2=dict(K=K2, D=[[-0.10, 0.04, -8e-4, 6e-4, 0.0]], xy=[W, H], name="cam2"),
+    )
+
+
+def scene_pair(seed=7, W=1280, H=720, cn=3):
+    """Unrectified-looking random textured pair for the full get_depth pipeline (content is
+    arbitrary: the parity tests only need identical inputs on both sides)."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (H, W + 64, cn), dtype=np.uint8)
+    base = _box3(_box3(base))
+    img1 = base[:, 64:].copy()
+    img2 = base[:, 40:40 + W].copy()
+    return img1, img2
