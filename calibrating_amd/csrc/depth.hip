@@ -1,0 +1,100 @@
+// depth.hip -- the NumPy post-processing around the matcher, fused into two gfx950 kernels.
+//
+// Replaces (file:line in /root/reference/calibrating/):
+//   stereo_matching.py:63-69   compute(...).astype(float32).clip(0); [< minD*16] = 0; /16.0;
+//                              boxx.resize (identity when max_size >= max(h,w)) * w / sw
+//   stereo_camera.py:510-512   disparity += min_disparity ; disparity = rectify_valid_mask1 * disparity
+//   stereo_camera.py:408-413   depth = 1.0*baseline*fx/disparity ; [> max_depth] = 0 ; [< 0] = 0
+//   utils.py:192-199           rotate_depth_by_remap: z' = (R @ inv(K) @ [x*z, y*z, z])[2], then
+//                              cv2.remap(..., INTER_NEAREST) through memoised maps
+// depth is float64 (what NumPy >= 2 produces for np.float64 scalar / float32 array).
+#include "common.hpp"
+
+namespace camd {
+
+__global__ __launch_bounds__(256) void k_disp_to_depth(const int16_t* __restrict__ disp16,
+                                                       const uint8_t* __restrict__ mask, int n,
+                                                       float thresh, float addv, int translate, float wf,
+                                                       double bf, double max_depth,
+                                                       float* __restrict__ disparity, double* __restrict__ depth)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    size_t o = (size_t)blockIdx.y * n + i;
+    float s = (float)disp16[o];
+    s = s < 0.f ? 0.f : s;
+    s = s < thresh ? 0.f : s;
+    float d = s / 16.0f;
+    d = __fdiv_rn(__fmul_rn(d, wf), wf);  // (d * w) / sw with sw == w, each op rounded like NumPy
+    if (translate) d = __fadd_rn(d, addv);
+    d = mask[i] ? d : __fmul_rn(0.f, d);
+    disparity[o] = d;
+    double z = __ddiv_rn(bf, (double)d);
+    z = z > max_depth ? 0. : z;
+    z = z < 0. ? 0. : z;
+    depth[o] = z;
+}
+
+__global__ __launch_bounds__(256) void k_unrectify(const double* __restrict__ depth, int w, int h, double m0,
+                                                   double m1, double m2, const float* __restrict__ mapx,
+                                                   const float* __restrict__ mapy, double* __restrict__ out,
+                                                   int ow, int oh)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= ow) return;
+    size_t mi = (size_t)y * ow + x;
+    int sx = min(max(__float2int_rn(mapx[mi]), -32768), 32767);
+    int sy = min(max(__float2int_rn(mapy[mi]), -32768), 32767);
+    double r = 0.;
+    if ((unsigned)sx < (unsigned)w && (unsigned)sy < (unsigned)h) {
+        double z = depth[(size_t)blockIdx.z * w * h + (size_t)sy * w + sx];
+        // M[2,0]*(x*z) + M[2,1]*(y*z) + M[2,2]*z, products and sums individually rounded
+        double a = __dmul_rn(m0, __dmul_rn((double)sx, z));
+        double b = __dmul_rn(m1, __dmul_rn((double)sy, z));
+        double c = __dmul_rn(m2, z);
+        r = __dadd_rn(__dadd_rn(a, b), c);
+    }
+    out[(size_t)blockIdx.z * ow * oh + mi] = r;
+}
+
+}  // namespace camd
+
+using namespace camd;
+
+extern "C" {
+
+int camd_disp_to_depth(const int16_t* disp16, const uint8_t* valid_mask, int w, int h,
+                       int sgbm_min_disparity, int add_min_disparity, int translate, double baseline_fx,
+                       double max_depth, float* disparity, double* depth, int batch, void* stream)
+{
+    if (!disp16 || !valid_mask || !disparity || !depth || w <= 0 || h <= 0 || batch <= 0) {
+        set_error("camd_disp_to_depth: bad arguments");
+        return CAMD_ERR_BAD_ARG;
+    }
+    int rc = camd_device_ok();
+    if (rc != CAMD_OK) return rc;
+    int n = w * h;
+    hipLaunchKernelGGL(k_disp_to_depth, dim3(div_up(n, 256), batch), dim3(256), 0, (hipStream_t)stream, disp16,
+                       valid_mask, n, (float)(sgbm_min_disparity * 16), (float)add_min_disparity, translate,
+                       (float)w, baseline_fx, max_depth, disparity, depth);
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
+int camd_unrectify_depth(const double* depth, int w, int h, const double M[3], const float* mapx,
+                         const float* mapy, double* out, int ow, int oh, int batch, void* stream)
+{
+    if (!depth || !M || !mapx || !mapy || !out || w <= 0 || h <= 0 || ow <= 0 || oh <= 0 || batch <= 0) {
+        set_error("camd_unrectify_depth: bad arguments");
+        return CAMD_ERR_BAD_ARG;
+    }
+    int rc = camd_device_ok();
+    if (rc != CAMD_OK) return rc;
+    hipLaunchKernelGGL(k_unrectify, dim3(div_up(ow, 256), oh, batch), dim3(256), 0, (hipStream_t)stream, depth,
+                       w, h, M[0], M[1], M[2], mapx, mapy, out, ow, oh);
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
+}  // extern "C"

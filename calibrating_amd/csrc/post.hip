@@ -1,0 +1,188 @@
+// post.hip -- the two filters cv2.StereoSGBM.compute applies after the dynamic programme:
+//   medianBlur(disp, disp, 3)  (unconditional; int16, replicate border)
+//   filterSpeckles(disp, (minD-1)*16, speckleWindowSize, 16*speckleRange)  iff speckleWindowSize > 0
+// Reference call site: /root/reference/calibrating/stereo_matching.py:63 (inside .compute).
+//
+// Speckle filter = connected components of the graph whose edges join 4-neighbours a, b with
+// a != newVal, b != newVal and |a - b| <= maxDiff; components of size <= maxSpeckleSize are
+// overwritten with newVal.  The relation is symmetric, so the components do not depend on OpenCV's
+// scan order and a lock-free union-find gives the identical result.
+#include "common.hpp"
+
+namespace camd {
+
+__device__ __forceinline__ void sort2(int& a, int& b)
+{
+    int t = min(a, b);
+    b = max(a, b);
+    a = t;
+}
+
+__global__ __launch_bounds__(256) void k_median3(const int16_t* __restrict__ src, size_t sp, size_t ss,
+                                                 int16_t* __restrict__ dst, size_t dp, size_t ds, int w, int h)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= w) return;
+    const int16_t* s = src + (size_t)blockIdx.z * ss;
+    int x0 = x > 0 ? x - 1 : x, x2 = x < w - 1 ? x + 1 : x;
+    const int16_t* r0 = s + (size_t)(y > 0 ? y - 1 : y) * sp;
+    const int16_t* r1 = s + (size_t)y * sp;
+    const int16_t* r2 = s + (size_t)(y < h - 1 ? y + 1 : y) * sp;
+    int p0 = r0[x0], p1 = r0[x], p2 = r0[x2];
+    int p3 = r1[x0], p4 = r1[x], p5 = r1[x2];
+    int p6 = r2[x0], p7 = r2[x], p8 = r2[x2];
+    // median of 9 by the classic 19-exchange network
+    sort2(p1, p2); sort2(p4, p5); sort2(p7, p8); sort2(p0, p1);
+    sort2(p3, p4); sort2(p6, p7); sort2(p1, p2); sort2(p4, p5);
+    sort2(p7, p8); sort2(p0, p3); sort2(p5, p8); sort2(p4, p7);
+    sort2(p3, p6); sort2(p1, p4); sort2(p2, p5); sort2(p4, p7);
+    sort2(p4, p2); sort2(p6, p4); sort2(p4, p2);
+    dst[(size_t)blockIdx.z * ds + (size_t)y * dp + x] = (int16_t)p4;
+}
+
+int launch_median3(const int16_t* src, size_t sp, size_t ss, int16_t* dst, size_t dp, size_t ds, int w, int h,
+                   int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_median3, dim3(div_up(w, 256), h, batch), dim3(256), 0, st, src, sp, ss, dst, dp, ds,
+                       w, h);
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
+// ---- union-find connected components --------------------------------------------------------------
+__device__ __forceinline__ int uf_find(int* parent, int a)
+{
+    int p = parent[a];
+    while (p != a) {
+        int gp = parent[p];
+        if (gp != p) parent[a] = gp;  // path halving (benign race: only ever points closer to the root)
+        a = p;
+        p = gp;
+    }
+    return a;
+}
+
+__device__ void uf_union(int* parent, int a, int b)
+{
+    while (true) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }  // a > b: hook the larger root under the smaller
+        int old = atomicCAS(&parent[a], a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_init(int* parent, int* count, int n)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        parent[i] = i;
+        count[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_merge(const int16_t* __restrict__ img, size_t pitch, int* parent,
+                                                  int w, int h, int new_val, int max_diff)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= w) return;
+    int v = img[(size_t)y * pitch + x];
+    if (v == new_val) return;
+    int i = y * w + x;
+    if (x + 1 < w) {
+        int r = img[(size_t)y * pitch + x + 1];
+        if (r != new_val && abs(v - r) <= max_diff) uf_union(parent, i, i + 1);
+    }
+    if (y + 1 < h) {
+        int d = img[(size_t)(y + 1) * pitch + x];
+        if (d != new_val && abs(v - d) <= max_diff) uf_union(parent, i, i + w);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_count(const int16_t* __restrict__ img, size_t pitch, int* parent,
+                                                  int* count, int w, int h, int new_val)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= w) return;
+    if (img[(size_t)y * pitch + x] == new_val) return;
+    int i = y * w + x;
+    int r = uf_find(parent, i);
+    parent[i] = r;
+    atomicAdd(&count[r], 1);
+}
+
+__global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, const int* __restrict__ parent,
+                                                  const int* __restrict__ count, int w, int h, int new_val,
+                                                  int max_size)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= w) return;
+    int16_t* p = img + (size_t)y * pitch + x;
+    if (*p == new_val) return;
+    int r = parent[y * w + x];
+    r = parent[r];  // parent[] was flattened to roots by k_cc_count; one extra hop is harmless
+    if (count[r] <= max_size) *p = (int16_t)new_val;
+}
+
+size_t speckle_ws_bytes(int w, int h, int batch)
+{
+    if (w <= 0 || h <= 0 || batch <= 0) return 0;
+    return (size_t)w * h * 2 * sizeof(int);  // parent + count, reused pair after pair
+}
+
+int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, int new_val, int max_size,
+                   int max_diff, void* ws, int batch, hipStream_t st)
+{
+    if (!ws) { set_error("speckle workspace is NULL"); return CAMD_ERR_BAD_ARG; }
+    int n = w * h;
+    int* parent = reinterpret_cast<int*>(ws);
+    int* count = parent + n;
+    dim3 grid(div_up(w, 256), h);
+    for (int b = 0; b < batch; b++) {
+        int16_t* im = img + (size_t)b * stride_e;
+        hipLaunchKernelGGL(k_cc_init, dim3(div_up(n, 256)), dim3(256), 0, st, parent, count, n);
+        hipLaunchKernelGGL(k_cc_merge, grid, dim3(256), 0, st, im, pitch_e, parent, w, h, new_val, max_diff);
+        hipLaunchKernelGGL(k_cc_count, grid, dim3(256), 0, st, im, pitch_e, parent, count, w, h, new_val);
+        hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), 0, st, im, pitch_e, parent, count, w, h, new_val,
+                           max_size);
+        CAMD_LAUNCH_CHECK();
+    }
+    return CAMD_OK;
+}
+
+}  // namespace camd
+
+using namespace camd;
+
+extern "C" {
+
+int camd_median3_s16(const int16_t* src, int16_t* dst, int w, int h, int batch, void* stream)
+{
+    if (!src || !dst || w <= 0 || h <= 0 || batch <= 0 || src == dst) {
+        set_error("camd_median3_s16: bad arguments (dst must differ from src)");
+        return CAMD_ERR_BAD_ARG;
+    }
+    return launch_median3(src, w, (size_t)w * h, dst, w, (size_t)w * h, w, h, batch, (hipStream_t)stream);
+}
+
+size_t camd_speckle_workspace_bytes(int w, int h, int batch) { return speckle_ws_bytes(w, h, batch); }
+
+int camd_filter_speckles_s16(int16_t* img, int w, int h, int new_val, int max_speckle_size, int max_diff,
+                             void* labels_ws, int batch, void* stream)
+{
+    if (!img || w <= 0 || h <= 0 || batch <= 0) {
+        set_error("camd_filter_speckles_s16: bad arguments");
+        return CAMD_ERR_BAD_ARG;
+    }
+    return launch_speckle(img, w, (size_t)w * h, w, h, new_val, max_speckle_size, max_diff, labels_ws, batch,
+                          (hipStream_t)stream);
+}
+
+}  // extern "C"

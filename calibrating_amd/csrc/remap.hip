@@ -1,0 +1,379 @@
+// remap.hip -- cv2.remap / cv2.undistort on 8-bit images for gfx950.
+//
+// Replaces (file:line in /root/reference/calibrating/):
+//   stereo_camera.py:217-228  cv2.remap(img, mapx, mapy, cv2.INTER_LANCZOS4)       (rectify, x2)
+//   stereo_camera.py:230-240  the x-translation of rectify_img2 (x_shift, fused)
+//   stereo_camera.py:430-431  cv2.undistort(img1, K, D)   (bilinear through 1/32-px fixed maps)
+// Arithmetic follows OpenCV's 8-bit fixed-point remap: 1/32-pixel phases, 15-bit int16 weights from
+// a 32x32-entry table (sum forced to 32768), int32 accumulate, (sum + 16384) >> 15, BORDER_CONSTANT 0.
+#include "common.hpp"
+
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+namespace camd {
+
+enum { INTER_BITS = 5, INTER_TAB_SIZE = 32, COEF_BITS = 15, COEF_SCALE = 1 << 15 };
+
+static inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+// 1-D Lanczos-4 weights at phase x in [0,1): taps at offsets -3..4
+static void lanczos4_1d(float x, float* coeffs)
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45},
+                                   {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    const double PI = 3.1415926535897932384626433832795;
+    float sum = 0;
+    double y0 = -(x + 3) * PI * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+    for (int i = 0; i < 8; i++) {
+        float y0_ = (x + 3 - i);
+        if (std::fabs(y0_) >= 1e-6f) {
+            double y = -y0_ * PI * 0.25;
+            coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        } else {
+            coeffs[i] = 1e30f;  // exact hit: takes all the weight after normalisation
+        }
+        sum += coeffs[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+// 2-D int16 table [32*32][ksize*ksize]; weights of every entry are corrected to sum to 32768 by
+// adjusting the largest (sum too small) or smallest (sum too large) tap of a central 2x2 group.
+static void build_itab(int ksize, int16_t* itab)
+{
+    std::vector<float> t1(8 * INTER_TAB_SIZE);
+    const float scale = 1.f / INTER_TAB_SIZE;
+    for (int i = 0; i < INTER_TAB_SIZE; i++) {
+        if (ksize == 8) lanczos4_1d(i * scale, &t1[i * 8]);
+        else { t1[i * 2] = 1.f - i * scale; t1[i * 2 + 1] = i * scale; }
+    }
+    // The correction scans taps k1,k2 in [ksize/2, ksize/2+2) relative to the entry (cv2's table
+    // builder).  For the 2x2 table that window runs into the entries that follow, which are still zero
+    // when the entry is processed; it only ever fires at phase (0,0), where the weight 32768 saturates
+    // to 32767 and the missing 1 lands on the (ksize/2, ksize/2) tap.
+    const int glo = ksize / 2;
+    int16_t* const tab0 = itab;
+    const long total = (long)INTER_TAB_SIZE * INTER_TAB_SIZE * ksize * ksize;
+    for (long q = 0; q < total; q++) itab[q] = 0;
+    for (int i = 0; i < INTER_TAB_SIZE; i++)
+        for (int j = 0; j < INTER_TAB_SIZE; j++, itab += ksize * ksize) {
+            int isum = 0;
+            for (int k1 = 0; k1 < ksize; k1++) {
+                float vy = t1[i * ksize + k1];
+                for (int k2 = 0; k2 < ksize; k2++) {
+                    float v = vy * t1[j * ksize + k2];
+                    isum += itab[k1 * ksize + k2] = sat_short((int)lrintf(v * COEF_SCALE));
+                }
+            }
+            if (isum != COEF_SCALE) {
+                int diff = isum - COEF_SCALE;
+                int Mk1 = glo, Mk2 = glo, mk1 = glo, mk2 = glo;
+                const long room = total - (itab - tab0);
+                for (int k1 = glo; k1 < glo + 2; k1++)
+                    for (int k2 = glo; k2 < glo + 2; k2++) {
+                        if (k1 * ksize + k2 >= room) continue;
+                        if (itab[k1 * ksize + k2] < itab[mk1 * ksize + mk2]) mk1 = k1, mk2 = k2;
+                        else if (itab[k1 * ksize + k2] > itab[Mk1 * ksize + Mk2]) Mk1 = k1, Mk2 = k2;
+                    }
+                if (diff < 0) itab[Mk1 * ksize + Mk2] = (short)(itab[Mk1 * ksize + Mk2] - diff);
+                else itab[mk1 * ksize + mk2] = (short)(itab[mk1 * ksize + mk2] - diff);
+            }
+        }
+}
+
+// device copies of the tables, one set per device, created on first use
+struct DevTables {
+    int16_t* lanczos = nullptr;
+    int16_t* bilinear = nullptr;
+};
+static std::mutex g_tab_mutex;
+static DevTables g_tabs[64];
+
+static int get_tables(const int16_t** lanczos, const int16_t** bilinear)
+{
+    int dev = 0;
+    CAMD_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("device index %d out of range", dev); return CAMD_ERR_HIP; }
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    DevTables& t = g_tabs[dev];
+    if (!t.lanczos) {
+        std::vector<int16_t> hl(1024 * 64), hb(1024 * 4);
+        build_itab(8, hl.data());
+        build_itab(2, hb.data());
+        int16_t *dl = nullptr, *db = nullptr;
+        CAMD_HIP(hipMalloc((void**)&dl, hl.size() * 2));
+        CAMD_HIP(hipMalloc((void**)&db, hb.size() * 2));
+        CAMD_HIP(hipMemcpy(dl, hl.data(), hl.size() * 2, hipMemcpyHostToDevice));
+        CAMD_HIP(hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+        t.lanczos = dl;
+        t.bilinear = db;
+    }
+    *lanczos = t.lanczos;
+    *bilinear = t.bilinear;
+    return CAMD_OK;
+}
+
+// one destination pixel: KS x KS taps at (ix, iy)..(ix+KS-1, iy+KS-1), weights w[KS*KS]
+template <int KS, int CN>
+__device__ __forceinline__ void gather_pixel(const uint8_t* __restrict__ src, int sw, int sh, size_t pitch,
+                                             int ix, int iy, const int16_t* __restrict__ w, uint8_t* out)
+{
+    int acc[CN];
+#pragma unroll
+    for (int c = 0; c < CN; c++) acc[c] = 0;
+    if (ix >= 0 && iy >= 0 && ix + KS <= sw && iy + KS <= sh) {
+#pragma unroll
+        for (int r = 0; r < KS; r++) {
+            const uint8_t* p = src + (size_t)(iy + r) * pitch + (size_t)ix * CN;
+#pragma unroll
+            for (int k = 0; k < KS; k++) {
+                int wt = w[r * KS + k];
+#pragma unroll
+                for (int c = 0; c < CN; c++) acc[c] += (int)p[k * CN + c] * wt;
+            }
+        }
+    } else if (!(ix >= sw || ix + KS <= 0 || iy >= sh || iy + KS <= 0)) {
+        for (int r = 0; r < KS; r++) {
+            int yy = iy + r;
+            if (yy < 0 || yy >= sh) continue;
+            const uint8_t* p = src + (size_t)yy * pitch;
+            for (int k = 0; k < KS; k++) {
+                int xx = ix + k;
+                if (xx < 0 || xx >= sw) continue;
+                int wt = w[r * KS + k];
+#pragma unroll
+                for (int c = 0; c < CN; c++) acc[c] += (int)p[(size_t)xx * CN + c] * wt;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+        int v = (acc[c] + (1 << (COEF_BITS - 1))) >> COEF_BITS;
+        out[c] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+template <int KS, int CN>
+__global__ __launch_bounds__(256) void k_remap_f32(const uint8_t* __restrict__ src, int sw, int sh,
+                                                   size_t src_pitch, size_t src_stride,
+                                                   const float* __restrict__ mapx,
+                                                   const float* __restrict__ mapy, uint8_t* __restrict__ dst,
+                                                   int dw, int dh, size_t dst_pitch, size_t dst_stride,
+                                                   const int16_t* __restrict__ tab, int x_shift)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= dw) return;
+    uint8_t* out = dst + (size_t)blockIdx.z * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN;
+    int xm = x - x_shift;
+    if (xm < 0 || xm >= dw) {
+#pragma unroll
+        for (int c = 0; c < CN; c++) out[c] = 0;
+        return;
+    }
+    size_t mi = (size_t)y * dw + xm;
+    // RemapInvoker: float map * 32 in float, cvRound (half to even), split into cell and phase
+    int sx = __float2int_rn(mapx[mi] * (float)INTER_TAB_SIZE);
+    int sy = __float2int_rn(mapy[mi] * (float)INTER_TAB_SIZE);
+    int a = (sy & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (sx & (INTER_TAB_SIZE - 1));
+    int ix = min(max(sx >> INTER_BITS, -32768), 32767) - (KS / 2 - 1);
+    int iy = min(max(sy >> INTER_BITS, -32768), 32767) - (KS / 2 - 1);
+    gather_pixel<KS, CN>(src + (size_t)blockIdx.z * src_stride, sw, sh, src_pitch, ix, iy,
+                         tab + (size_t)a * (KS * KS), out);
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_remap_nearest_u8(const uint8_t* __restrict__ src, int sw, int sh,
+                                                          size_t src_pitch, size_t src_stride,
+                                                          const float* __restrict__ mapx,
+                                                          const float* __restrict__ mapy,
+                                                          uint8_t* __restrict__ dst, int dw, int dh,
+                                                          size_t dst_pitch, size_t dst_stride, int x_shift)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= dw) return;
+    uint8_t* out = dst + (size_t)blockIdx.z * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN;
+    int xm = x - x_shift;
+    bool ok = xm >= 0 && xm < dw;
+    int sx = 0, sy = 0;
+    if (ok) {
+        size_t mi = (size_t)y * dw + xm;
+        sx = min(max(__float2int_rn(mapx[mi]), -32768), 32767);
+        sy = min(max(__float2int_rn(mapy[mi]), -32768), 32767);
+        ok = (unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh;
+    }
+    const uint8_t* p = src + (size_t)blockIdx.z * src_stride + (size_t)sy * src_pitch + (size_t)sx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) out[c] = ok ? p[c] : 0;
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_remap_fixed_bilinear(const uint8_t* __restrict__ src, int sw, int sh,
+                                                              size_t src_pitch, size_t src_stride,
+                                                              const int16_t* __restrict__ mapxy,
+                                                              const uint16_t* __restrict__ mapa,
+                                                              uint8_t* __restrict__ dst, int dw, int dh,
+                                                              size_t dst_pitch, size_t dst_stride,
+                                                              const int16_t* __restrict__ tab)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= dw) return;
+    size_t mi = (size_t)y * dw + x;
+    int ix = mapxy[mi * 2], iy = mapxy[mi * 2 + 1];
+    int a = mapa[mi] & (INTER_TAB_SIZE * INTER_TAB_SIZE - 1);
+    gather_pixel<2, CN>(src + (size_t)blockIdx.z * src_stride, sw, sh, src_pitch, ix, iy, tab + (size_t)a * 4,
+                        dst + (size_t)blockIdx.z * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN);
+}
+
+// host: one row of initUndistortRectifyMap's inner loop (X/Y/W accumulate per column, float64)
+struct Dist { double k1, k2, p1, p2, k3, k4, k5, k6, s1, s2, s3, s4; };
+
+static void inv3(const double m[9], double o[9])
+{
+    double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+               m[2] * (m[3] * m[7] - m[4] * m[6]);
+    d = d != 0. ? 1. / d : 0.;
+    double t[9] = {(m[4] * m[8] - m[5] * m[7]) * d, (m[2] * m[7] - m[1] * m[8]) * d,
+                   (m[1] * m[5] - m[2] * m[4]) * d, (m[5] * m[6] - m[3] * m[8]) * d,
+                   (m[0] * m[8] - m[2] * m[6]) * d, (m[2] * m[3] - m[0] * m[5]) * d,
+                   (m[3] * m[7] - m[4] * m[6]) * d, (m[1] * m[6] - m[0] * m[7]) * d,
+                   (m[0] * m[4] - m[1] * m[3]) * d};
+    for (int i = 0; i < 9; i++) o[i] = t[i];
+}
+
+}  // namespace camd
+
+using namespace camd;
+
+extern "C" {
+
+int camd_lanczos4_table_host(int16_t* tab)
+{
+    if (!tab) { set_error("NULL table"); return CAMD_ERR_BAD_ARG; }
+    build_itab(8, tab);
+    return CAMD_OK;
+}
+
+int camd_bilinear_table_host(int16_t* tab)
+{
+    if (!tab) { set_error("NULL table"); return CAMD_ERR_BAD_ARG; }
+    build_itab(2, tab);
+    return CAMD_OK;
+}
+
+int camd_remap_u8(const uint8_t* src, int sw, int sh, int cn, size_t src_pitch, size_t src_stride,
+                  const float* mapx, const float* mapy, uint8_t* dst, int dw, int dh, size_t dst_pitch,
+                  size_t dst_stride, int interp, int x_shift, int batch, void* stream)
+{
+    if (!src || !mapx || !mapy || !dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || batch <= 0 ||
+        (cn != 1 && cn != 3) || src_pitch < (size_t)sw * cn || dst_pitch < (size_t)dw * cn) {
+        set_error("camd_remap_u8: bad arguments");
+        return CAMD_ERR_BAD_ARG;
+    }
+    int rc = camd_device_ok();
+    if (rc != CAMD_OK) return rc;
+    const int16_t *tl = nullptr, *tb = nullptr;
+    rc = get_tables(&tl, &tb);
+    if (rc != CAMD_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(div_up(dw, 256), dh, batch), block(256);
+#define ARGS src, sw, sh, src_pitch, src_stride, mapx, mapy, dst, dw, dh, dst_pitch, dst_stride
+    if (interp == CAMD_INTER_LANCZOS4) {
+        if (cn == 1) hipLaunchKernelGGL((k_remap_f32<8, 1>), grid, block, 0, st, ARGS, tl, x_shift);
+        else hipLaunchKernelGGL((k_remap_f32<8, 3>), grid, block, 0, st, ARGS, tl, x_shift);
+    } else if (interp == CAMD_INTER_LINEAR) {
+        if (cn == 1) hipLaunchKernelGGL((k_remap_f32<2, 1>), grid, block, 0, st, ARGS, tb, x_shift);
+        else hipLaunchKernelGGL((k_remap_f32<2, 3>), grid, block, 0, st, ARGS, tb, x_shift);
+    } else if (interp == CAMD_INTER_NEAREST) {
+        if (cn == 1) hipLaunchKernelGGL((k_remap_nearest_u8<1>), grid, block, 0, st, ARGS, x_shift);
+        else hipLaunchKernelGGL((k_remap_nearest_u8<3>), grid, block, 0, st, ARGS, x_shift);
+    } else {
+        set_error("camd_remap_u8: interpolation %d not implemented", interp);
+        return CAMD_ERR_UNSUPPORTED;
+    }
+#undef ARGS
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
+int camd_remap_fixed_bilinear_u8(const uint8_t* src, int sw, int sh, int cn, size_t src_pitch,
+                                 size_t src_stride, const int16_t* mapxy, const uint16_t* mapa, uint8_t* dst,
+                                 int dw, int dh, size_t dst_pitch, size_t dst_stride, int batch, void* stream)
+{
+    if (!src || !mapxy || !mapa || !dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || batch <= 0 ||
+        (cn != 1 && cn != 3) || src_pitch < (size_t)sw * cn || dst_pitch < (size_t)dw * cn) {
+        set_error("camd_remap_fixed_bilinear_u8: bad arguments");
+        return CAMD_ERR_BAD_ARG;
+    }
+    int rc = camd_device_ok();
+    if (rc != CAMD_OK) return rc;
+    const int16_t *tl = nullptr, *tb = nullptr;
+    rc = get_tables(&tl, &tb);
+    if (rc != CAMD_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(div_up(dw, 256), dh, batch), block(256);
+    if (cn == 1)
+        hipLaunchKernelGGL((k_remap_fixed_bilinear<1>), grid, block, 0, st, src, sw, sh, src_pitch, src_stride,
+                           mapxy, mapa, dst, dw, dh, dst_pitch, dst_stride, tb);
+    else
+        hipLaunchKernelGGL((k_remap_fixed_bilinear<3>), grid, block, 0, st, src, sw, sh, src_pitch, src_stride,
+                           mapxy, mapa, dst, dw, dh, dst_pitch, dst_stride, tb);
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
+int camd_undistort_maps_host(const double K[9], const double* dist, int ndist, int w, int h,
+                             int16_t* mapxy, uint16_t* mapa)
+{
+    if (!K || !mapxy || !mapa || w <= 0 || h <= 0 || ndist < 0 || ndist > 14 || (ndist > 0 && !dist)) {
+        set_error("camd_undistort_maps_host: bad arguments");
+        return CAMD_ERR_BAD_ARG;
+    }
+    double dv[14] = {0};
+    for (int i = 0; i < ndist; i++) dv[i] = dist[i];
+    if (ndist > 12 && (dv[12] != 0. || dv[13] != 0.)) {
+        set_error("tilted-sensor distortion (tauX, tauY) not implemented");
+        return CAMD_ERR_UNSUPPORTED;
+    }
+    const Dist k = {dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], dv[7], dv[8], dv[9], dv[10], dv[11]};
+    // cv2.undistort works in stripes of rows and folds the stripe offset into the new camera matrix
+    int stripe0 = (1 << 12) / (w > 1 ? w : 1);
+    if (stripe0 < 1) stripe0 = 1;
+    if (stripe0 > h) stripe0 = h;
+    double Ar[9], ir[9];
+    for (int i = 0; i < 9; i++) Ar[i] = K[i];
+    const double fx = K[0], fy = K[4], u0 = K[2], v0 = K[5], cy0 = K[5];
+    for (int y = 0; y < h; y += stripe0) {
+        int stripe = stripe0 < h - y ? stripe0 : h - y;
+        Ar[5] = cy0 - y;
+        inv3(Ar, ir);
+        for (int i = 0; i < stripe; i++) {
+            double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+            int16_t* mxy = mapxy + (size_t)(y + i) * w * 2;
+            uint16_t* ma = mapa + (size_t)(y + i) * w;
+            for (int j = 0; j < w; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+                double ww = 1. / _w, x = _x * ww, yy = _y * ww;
+                double x2 = x * x, y2 = yy * yy;
+                double r2 = x2 + y2, _2xy = 2 * x * yy;
+                double kr = (1 + ((k.k3 * r2 + k.k2) * r2 + k.k1) * r2) /
+                            (1 + ((k.k6 * r2 + k.k5) * r2 + k.k4) * r2);
+                double xd = (x * kr + k.p1 * _2xy + k.p2 * (r2 + 2 * x2) + k.s1 * r2 + k.s2 * r2 * r2);
+                double yd = (yy * kr + k.p1 * (r2 + 2 * y2) + k.p2 * _2xy + k.s3 * r2 + k.s4 * r2 * r2);
+                double u = fx * xd + u0, v = fy * yd + v0;
+                int iu = (int)lrint(u * INTER_TAB_SIZE), iv = (int)lrint(v * INTER_TAB_SIZE);
+                mxy[j * 2] = (int16_t)(iu >> INTER_BITS);
+                mxy[j * 2 + 1] = (int16_t)(iv >> INTER_BITS);
+                ma[j] = (uint16_t)((iv & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (iu & (INTER_TAB_SIZE - 1)));
+            }
+        }
+    }
+    return CAMD_OK;
+}
+
+}  // extern "C"

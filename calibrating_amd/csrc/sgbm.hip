@@ -1,0 +1,811 @@
+// sgbm.hip -- Semi-Global Block Matching for gfx950 (MI355X), bit-exact with cv2.StereoSGBM
+// (modes MODE_SGBM and MODE_HH) at equal parameters.
+//
+// Replaces the cv2.StereoSGBM_create(...).compute(left, right) call of the reference
+// (/root/reference/calibrating/stereo_matching.py:48-58,63).  Not a port of OpenCV's row-incremental
+// CPU loop: the algorithm is re-stated in a data-parallel form (SURVEY.md Appendix A / DESIGN.md):
+//
+//   k_bt_prepare   per pixel: clipped x-Sobel + raw planes and their half-pixel min/max, packed as
+//                  (gradient | raw << 16) u16 pairs so the BT cost runs on packed 16-bit VALU ops
+//   k_hsum         Birchfield-Tomasi cost + horizontal box sum.  One wave = 64 consecutive
+//                  disparities of one row; the right-image operands live in a wave-wide shift
+//                  register (DPP wave_shr:1), the left-image operands are wave-uniform scalars
+//   k_vsum         vertical box sum + P2  ->  C[y][x][d]  (int16, d fastest)
+//   k_scan         one aggregation direction as independent line scans from a zero border state;
+//                  a line is owned by a 2..16-lane group (8*NV disparities per lane, packed u16x2),
+//                  neighbours d-1 / d+1 by DPP row shifts, min over d by a DPP butterfly
+//   k_wta          winner-take-all, uniqueness, sub-pixel parabola, right-view map via LDS
+//                  atomicMin on (cost << 16 | 0xFFFF - d), left-right check; one workgroup per row
+//   k_median3 / speckle (post.hip)
+//
+// All volumes are [pair][y][x][Dp] int16 with Dp = LANES*8*NV >= D; entries d >= D carry MAX_COST.
+#include "common.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace camd {
+
+static constexpr uint32_t SENT_PK = 0x7fff7fffu;  // MAX_COST in both halves
+static constexpr int MAX_COST = 32767;
+
+struct Geom {
+    int W, H, cn;          // image
+    int minD, D, Dp;       // disparity range, padded
+    int minX1, W1;         // cost coordinates: x_img = x + minX1
+    int SW2;               // box radius
+    int P1, P2, uniq, d12; // normalised parameters
+    int ftzero;
+    int lanes, nv;         // line-group shape: Dp = lanes*8*nv
+    int mode, npaths;
+    int speckleWindowSize, speckleRange;
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_bt_prepare: planes of calcPixelCostBT, per pixel and channel: 3 dwords
+//   [0] = p   (gradient | raw<<16),  [1] = min(p, (p+left)/2, (p+right)/2),  [2] = max(...)
+// Columns 0 and W-1 of every plane hold ftzero (= tab[0]).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int plane_grad(const uint8_t* __restrict__ r0, const uint8_t* __restrict__ rm,
+                                          const uint8_t* __restrict__ rp, int x, int W, int cn, int c,
+                                          int ftzero)
+{
+    if (x <= 0 || x >= W - 1) return ftzero;
+    int a = x * cn + c;
+    int g = ((int)r0[a + cn] - (int)r0[a - cn]) * 2 + ((int)rm[a + cn] - (int)rm[a - cn]) +
+            ((int)rp[a + cn] - (int)rp[a - cn]);
+    g = min(max(g, -ftzero), ftzero) + ftzero;
+    return g;
+}
+__device__ __forceinline__ int plane_raw(const uint8_t* __restrict__ r0, int x, int W, int cn, int c,
+                                         int ftzero)
+{
+    if (x <= 0 || x >= W - 1) return ftzero;
+    return r0[x * cn + c];
+}
+
+__global__ __launch_bounds__(256) void k_bt_prepare(const uint8_t* __restrict__ left,
+                                                    const uint8_t* __restrict__ right, size_t pitch,
+                                                    size_t image_stride, uint32_t* __restrict__ Lpk,
+                                                    uint32_t* __restrict__ Rpk, int W, int H, int cn,
+                                                    int ftzero)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    int pair = blockIdx.z >> 1, which = blockIdx.z & 1;
+    if (x >= W) return;
+    const uint8_t* img = (which ? right : left) + (size_t)pair * image_stride;
+    uint32_t* out = (which ? Rpk : Lpk) + ((size_t)pair * H * W + (size_t)y * W + x) * (size_t)(cn * 3);
+    const uint8_t* r0 = img + (size_t)y * pitch;
+    const uint8_t* rm = img + (size_t)(y > 0 ? y - 1 : y) * pitch;
+    const uint8_t* rp = img + (size_t)(y < H - 1 ? y + 1 : y) * pitch;
+    for (int c = 0; c < cn; c++) {
+        int g = plane_grad(r0, rm, rp, x, W, cn, c, ftzero);
+        int r = plane_raw(r0, x, W, cn, c, ftzero);
+        int gl = g, gr = g, rl = r, rr = r;
+        if (x > 0) {
+            gl = (g + plane_grad(r0, rm, rp, x - 1, W, cn, c, ftzero)) / 2;
+            rl = (r + plane_raw(r0, x - 1, W, cn, c, ftzero)) / 2;
+        }
+        if (x < W - 1) {
+            gr = (g + plane_grad(r0, rm, rp, x + 1, W, cn, c, ftzero)) / 2;
+            rr = (r + plane_raw(r0, x + 1, W, cn, c, ftzero)) / 2;
+        }
+        int g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
+        int q0 = min(min(rl, rr), r), q1 = max(max(rl, rr), r);
+        out[c * 3 + 0] = (uint32_t)g | ((uint32_t)r << 16);
+        out[c * 3 + 1] = (uint32_t)g0 | ((uint32_t)q0 << 16);
+        out[c * 3 + 2] = (uint32_t)g1 | ((uint32_t)q1 << 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hsum: Hs[y][x][d] = sum_{dx=-SW2..SW2} pix(y, clamp(x+dx, 0, W1-1), d)   (u16, wraps like
+// OpenCV's CostType), pix = sum over channels of min(c0, c1) [gradient] + min(c0, c1) >> 2 [raw].
+// One wave: row y, 64 consecutive d (lane j <-> d = dblk*64 + j), cost columns [xs, xe).
+// ------------------------------------------------------------------------------------------------
+static constexpr int HSUM_SEG = 128;   // cost columns per wave
+static constexpr int HSUM_WAVES = 4;   // waves per workgroup
+static constexpr int HSUM_RING = 16;   // ring slots (>= 2*SW2+1), per lane, in LDS
+
+template <int CN>
+__global__ __launch_bounds__(64 * HSUM_WAVES) void k_hsum(const uint32_t* __restrict__ Lpk,
+                                                          const uint32_t* __restrict__ Rpk,
+                                                          uint16_t* __restrict__ Hs, Geom g, int nseg,
+                                                          int ndblk, size_t vol_stride)
+{
+    __shared__ uint32_t ring[HSUM_WAVES][HSUM_RING][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // work item = (segment, dblk) of row y
+    int item = blockIdx.x * HSUM_WAVES + wv;
+    if (item >= nseg * ndblk) return;  // whole wave exits
+    const int seg = item / ndblk, dblk = item % ndblk;
+    const int y = blockIdx.y, pair = blockIdx.z;
+    const int xs = seg * HSUM_SEG, xe = min(xs + HSUM_SEG, g.W1);
+    const int d = dblk * 64 + lane;
+    const int K = 2 * g.SW2 + 1;
+    const size_t rowbase = ((size_t)pair * g.H + y) * (size_t)g.W;
+    const uint32_t* __restrict__ Lrow = Lpk + rowbase * (CN * 3);
+    const uint32_t* __restrict__ Rrow = Rpk + rowbase * (CN * 3);
+    uint16_t* __restrict__ out = Hs + (size_t)pair * vol_stride + ((size_t)y * g.W1) * g.Dp + d;
+    const bool wr_valid = d < g.D, wr_pad = d < g.Dp;
+
+    // first real cost column visited and its right-image column for this lane
+    int t0 = xs - g.SW2;
+    int c0 = min(max(t0, 0), g.W1 - 1);
+    uint32_t V[CN], V0[CN], V1[CN];
+    {
+        int xr = c0 + g.minX1 - d - g.minD;
+        xr = min(max(xr, 0), g.W - 1);  // lanes with d >= D may point outside; value unused
+        const uint32_t* p = Rrow + (size_t)xr * (CN * 3);
+#pragma unroll
+        for (int c = 0; c < CN; c++) { V[c] = p[c * 3]; V0[c] = p[c * 3 + 1]; V1[c] = p[c * 3 + 2]; }
+    }
+    for (int s = 0; s < HSUM_RING; s++) ring[wv][s][lane] = 0;
+
+    uint32_t run = 0, pix = 0;
+    int cur = c0 - 1;  // forces evaluation at the first step
+    int slot = 0;
+    const int t1 = xe - 1 + g.SW2;
+    for (int t = t0; t <= t1; t++) {
+        int ct = min(max(t, 0), g.W1 - 1);
+        if (ct != cur) {  // wave-uniform
+            if (cur >= c0) {
+                // advance the shift register: lane j takes lane j-1's operands, lane 0 the new column
+                int xr0 = __builtin_amdgcn_readfirstlane(ct + g.minX1 - dblk * 64 - g.minD);
+                xr0 = min(max(xr0, 0), g.W - 1);
+                const uint32_t* p = Rrow + (size_t)xr0 * (CN * 3);
+#pragma unroll
+                for (int c = 0; c < CN; c++) {
+                    V[c] = dpp_mov<DPP_WAVE_SHR1>(p[c * 3], V[c]);
+                    V0[c] = dpp_mov<DPP_WAVE_SHR1>(p[c * 3 + 1], V0[c]);
+                    V1[c] = dpp_mov<DPP_WAVE_SHR1>(p[c * 3 + 2], V1[c]);
+                }
+            }
+            cur = ct;
+            const uint32_t* q = Lrow + (size_t)__builtin_amdgcn_readfirstlane(ct + g.minX1) * (CN * 3);
+            uint32_t acc = 0;
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                uint32_t U = q[c * 3], U0 = q[c * 3 + 1], U1 = q[c * 3 + 2];
+                // c0 = max(0, u - v1, v0 - u), c1 = max(0, v - u1, u0 - v): at most one term of each
+                // pair is non-zero, so OR of the saturating differences is their max
+                uint32_t a = pk_subsat_u16(U, V1[c]) | pk_subsat_u16(V0[c], U);
+                uint32_t b = pk_subsat_u16(V[c], U1) | pk_subsat_u16(U0, V[c]);
+                uint32_t m = pk_min_u16(a, b);
+                m = pk_lshr_u16(m, 0x00020000u);  // raw plane: cost >> 2
+                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, m),
+                                             __builtin_bit_cast(u16x2_t, 0x00010001u), acc, false);
+            }
+            pix = acc;
+        }
+        uint32_t old = ring[wv][slot][lane];
+        ring[wv][slot][lane] = pix;
+        slot = slot + 1 == K ? 0 : slot + 1;
+        run += pix - old;
+        int xo = t - g.SW2;
+        if (xo >= xs) {
+            uint16_t* o = out + (size_t)xo * g.Dp;
+            if (wr_valid) *o = (uint16_t)run;
+            else if (wr_pad) *o = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_vsum: C[y][x][d] = P2 + sum_{dy=-SH2..SH2} Hs[clamp(y+dy,0,H-1)][x][d]   (u16 wrap)
+// One thread = 8 consecutive d (16 bytes).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vsum(const uint4* __restrict__ Hs, uint4* __restrict__ C, Geom g,
+                                              size_t vol_stride16)
+{
+    const size_t rowv = (size_t)g.W1 * (g.Dp / 8);  // uint4 per row
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rowv) return;
+    const int y = blockIdx.y, pair = blockIdx.z;
+    const uint4* base = Hs + (size_t)pair * vol_stride16;
+    uint32_t p2 = dup16((uint32_t)g.P2);
+    uint4 acc = make_uint4(p2, p2, p2, p2);
+    for (int dy = -g.SW2; dy <= g.SW2; dy++) {
+        int yy = min(max(y + dy, 0), g.H - 1);
+        uint4 v = base[(size_t)yy * rowv + i];
+        acc.x = pk_add_u16(acc.x, v.x);
+        acc.y = pk_add_u16(acc.y, v.y);
+        acc.z = pk_add_u16(acc.z, v.z);
+        acc.w = pk_add_u16(acc.w, v.w);
+    }
+    C[(size_t)pair * vol_stride16 + (size_t)y * rowv + i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan: L_r along direction r = (dx, dy) for every line of the cost array, accumulated into S.
+//   L(p,d) = C(p,d) + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, minLp+P2) - (minLp+P2),  Lp = L(p-r,.)
+//   Lp = 0, minLp = 0 outside the array; Lp[-1] = Lp[D] = MAX_COST.
+// A line is owned by LANES lanes; lane l holds d in [l*8*NV, (l+1)*8*NV) as 4*NV packed u16 pairs.
+// All arithmetic is u16: real values are in [0, 32767], MAX_COST + P1 does not wrap, and the final
+// (C + m) - delta is exact modulo 2^16 (OpenCV's (CostType) cast).
+// ------------------------------------------------------------------------------------------------
+template <int LANES, int NV, bool FIRST, bool PAD>
+__global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, uint16_t* __restrict__ Sv,
+                                              Geom g, int dx, int dy, int nlines, size_t vol_stride)
+{
+    constexpr int NR = 4 * NV;
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int line = tid / LANES, li = tid % LANES;
+    if (line >= nlines) return;
+    const int pair = blockIdx.y;
+    const int W1 = g.W1, H = g.H;
+
+    // start pixel and length of this line
+    int x0, y0;
+    if (dy == 0) {
+        y0 = line;
+        x0 = dx > 0 ? 0 : W1 - 1;
+    } else {
+        const int ys = dy > 0 ? 0 : H - 1;
+        if (dx == 0 || line < W1) {
+            x0 = line;
+            y0 = ys;
+        } else {
+            x0 = dx > 0 ? 0 : W1 - 1;
+            int k = line - W1 + 1;  // 1..H-1
+            y0 = dy > 0 ? k : H - 1 - k;
+        }
+    }
+    int len;
+    {
+        int lx = dx == 0 ? (1 << 30) : (dx > 0 ? W1 - x0 : x0 + 1);
+        int ly = dy == 0 ? (1 << 30) : (dy > 0 ? H - y0 : y0 + 1);
+        len = min(lx, ly);
+    }
+    const size_t off = (size_t)pair * vol_stride + ((size_t)y0 * W1 + x0) * g.Dp + (size_t)li * (8 * NV);
+    const ptrdiff_t step = ((ptrdiff_t)dy * W1 + dx) * (ptrdiff_t)g.Dp;
+    const uint4* cp = reinterpret_cast<const uint4*>(Cv + off);
+    uint4* sp = reinterpret_cast<uint4*>(Sv + off);
+    const ptrdiff_t step4 = step / 8;
+
+    uint32_t keep[NR], sent[NR];
+    if (PAD) {
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            int d0 = li * 8 * NV + 2 * k;
+            uint32_t kp = (d0 < g.D ? 0xffffu : 0u) | (d0 + 1 < g.D ? 0xffff0000u : 0u);
+            keep[k] = kp;
+            sent[k] = ~kp & SENT_PK;
+        }
+    }
+
+    const uint32_t P1pk = dup16((uint32_t)g.P1), P2pk = dup16((uint32_t)g.P2);
+    uint32_t Lp[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) Lp[k] = 0;
+    uint32_t delta = P2pk;  // minLp = 0
+
+    uint32_t c[NR], s[NR];
+    auto load = [&](const uint4* p, uint32_t* dst) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            uint4 q = p[v];
+            dst[4 * v] = q.x; dst[4 * v + 1] = q.y; dst[4 * v + 2] = q.z; dst[4 * v + 3] = q.w;
+        }
+    };
+    load(cp, c);
+    if (!FIRST) load(sp, s);
+
+    for (int i = 0; i < len; i++) {
+        // prefetch the next pixel of the line
+        uint32_t cn_[NR], sn_[NR];
+        const bool more = i + 1 < len;
+        if (more) {
+            load(cp + step4, cn_);
+            if (!FIRST) load(sp + step4, sn_);
+        }
+        // neighbours across lanes: d-1 of my first element, d+1 of my last element
+        uint32_t prev_last = dpp_mov<DPP_ROW_SHR1>(SENT_PK, Lp[NR - 1]);
+        uint32_t next_first = dpp_mov<DPP_ROW_SHL1>(SENT_PK, Lp[0]);
+        if (LANES < 16) {
+            if (li == 0) prev_last = SENT_PK;
+            if (li == LANES - 1) next_first = SENT_PK;
+        }
+        // m[k] = (Lp[2k-1], Lp[2k]) ; m[k+1] = (Lp[2k+1], Lp[2k+2])
+        uint32_t m[NR + 1];
+        m[0] = alignbit16(Lp[0], prev_last);
+#pragma unroll
+        for (int k = 1; k < NR; k++) m[k] = alignbit16(Lp[k], Lp[k - 1]);
+        m[NR] = alignbit16(next_first, Lp[NR - 1]);
+
+        uint32_t L[NR];
+        uint32_t mn = SENT_PK;
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            uint32_t t = pk_add_u16(pk_min_u16(m[k], m[k + 1]), P1pk);
+            uint32_t a = pk_min_u16(pk_min_u16(Lp[k], t), delta);
+            uint32_t l = pk_sub_u16(pk_add_u16(c[k], a), delta);
+            if (PAD) l = (l & keep[k]) | sent[k];
+            L[k] = l;
+            mn = pk_min_u16(mn, l);
+        }
+        mn = group_min_pk_u16<LANES>(mn);
+        mn = pk_min_u16(mn, alignbit16(mn, mn));  // both halves = min over all d
+        delta = pk_add_u16(mn, P2pk);
+
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            s[k] = FIRST ? L[k] : pk_addsat_i16(s[k], L[k]);
+            Lp[k] = L[k];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) sp[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
+
+        cp += step4;
+        sp += step4;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < NR; k++) {
+                c[k] = cn_[k];
+                if (!FIRST) s[k] = sn_[k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_wta: one workgroup per image row.  Per cost column x (a LANES-lane group each):
+//   minS / bestDisp (smallest d attaining it), uniqueness test, sub-pixel parabola,
+//   right-view map disp2 by LDS atomicMin on (minS << 16 | 0xFFFF - d)  [ties keep the larger d,
+//   i.e. the larger x, which OpenCV visits first], then the left-right check of the row.
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t KEY_INIT = 0x7fff0000u;
+
+template <int LANES, int NV>
+__global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, int16_t* __restrict__ disp,
+                                             size_t disp_pitch_e, size_t disp_stride_e, Geom g,
+                                             size_t vol_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);          // [W]
+    int16_t* d1row = reinterpret_cast<int16_t*>(keys + g.W);     // [W]
+    constexpr int NR = 4 * NV;
+    constexpr int GROUPS = 256 / LANES;
+    const int y = blockIdx.x, pair = blockIdx.y;
+    const int li = threadIdx.x % LANES, grp = threadIdx.x / LANES;
+    const int INVALID_SCALED = (g.minD - 1) * 16;
+
+    for (int x = threadIdx.x; x < g.W; x += 256) {
+        keys[x] = KEY_INIT;
+        d1row[x] = (int16_t)INVALID_SCALED;
+    }
+    __syncthreads();
+
+    const uint16_t* Srow = Sv + (size_t)pair * vol_stride + ((size_t)y * g.W1) * g.Dp + (size_t)li * (8 * NV);
+    const int dbase = li * 8 * NV;
+    for (int x = grp; x < g.W1; x += GROUPS) {
+        uint32_t s[NR];
+        const uint4* p = reinterpret_cast<const uint4*>(Srow + (size_t)x * g.Dp);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            uint4 q = p[v];
+            s[4 * v] = q.x; s[4 * v + 1] = q.y; s[4 * v + 2] = q.z; s[4 * v + 3] = q.w;
+        }
+        // (S << 16 | d) minimum: smallest S, then smallest d
+        uint32_t key = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            int d0 = dbase + 2 * k;
+            uint32_t lo = s[k] & 0xffffu, hi = s[k] >> 16;
+            if (d0 < g.D) key = min(key, (lo << 16) | (uint32_t)d0);
+            if (d0 + 1 < g.D) key = min(key, (hi << 16) | (uint32_t)(d0 + 1));
+        }
+        key = group_min_u32<LANES>(key);
+        const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
+        // uniqueness + the neighbours of the winner
+        uint32_t flags = 0, sm = 0, spv = 0;
+        const int thr = minS * 100, mul = 100 - g.uniq;
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            int d0 = dbase + 2 * k;
+            int lo = (int)(s[k] & 0xffffu), hi = (int)(s[k] >> 16);
+            if (d0 < g.D) {
+                if (lo * mul < thr && abs(best - d0) > 1) flags = 1;
+                if (d0 == best - 1) sm = (uint32_t)lo;
+                if (d0 == best + 1) spv = (uint32_t)lo;
+            }
+            if (d0 + 1 < g.D) {
+                if (hi * mul < thr && abs(best - d0 - 1) > 1) flags = 1;
+                if (d0 + 1 == best - 1) sm = (uint32_t)hi;
+                if (d0 + 1 == best + 1) spv = (uint32_t)hi;
+            }
+        }
+        uint32_t packed = group_or_u32<LANES>((flags << 31) | (sm << 15) | spv);  // S values < 2^15
+        if (li == 0 && minS < MAX_COST && !(packed >> 31)) {
+            int Sm = (int)((packed >> 15) & 0x7fffu), Sp = (int)(packed & 0x7fffu);
+            int d = best;
+            int x2 = x + g.minX1 - d - g.minD;
+            atomicMin(&keys[x2], ((uint32_t)minS << 16) | (uint32_t)(0xffff - d));
+            if (0 < d && d < g.D - 1) {
+                int denom2 = max(Sm + Sp - 2 * minS, 1);
+                d = d * 16 + ((Sm - Sp) * 16 + denom2) / (denom2 * 2);  // C division truncates
+            } else
+                d *= 16;
+            d1row[x + g.minX1] = (int16_t)(d + g.minD * 16);
+        }
+    }
+    __syncthreads();
+
+    int16_t* out = disp + (size_t)pair * disp_stride_e + (size_t)y * disp_pitch_e;
+    const int maxX1 = g.minX1 + g.W1;
+    for (int x = threadIdx.x; x < g.W; x += 256) {
+        int d1 = d1row[x];
+        if (x >= g.minX1 && x < maxX1 && d1 != INVALID_SCALED) {
+            int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
+            int _x = x - _d, x_ = x - d_;
+            bool bad = true;
+            if (0 <= _x && _x < g.W) {
+                uint32_t k = keys[_x];
+                // untouched entries hold INVALID_DISP_SCALED and are compared unscaled (OpenCV quirk)
+                int v = k == KEY_INIT ? INVALID_SCALED : (int)(0xffffu - (k & 0xffffu)) + g.minD;
+                bad = v >= g.minD && abs(v - _d) > g.d12;
+            } else
+                bad = false;
+            if (bad) {
+                if (0 <= x_ && x_ < g.W) {
+                    uint32_t k = keys[x_];
+                    int v = k == KEY_INIT ? INVALID_SCALED : (int)(0xffffu - (k & 0xffffu)) + g.minD;
+                    bad = v >= g.minD && abs(v - d_) > g.d12;
+                } else
+                    bad = false;
+            }
+            if (bad) d1 = INVALID_SCALED;
+        }
+        out[x] = (int16_t)d1;
+    }
+}
+
+__global__ void k_fill_s16(int16_t* p, size_t pitch_e, size_t stride_e, int W, int H, int value)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    if (x < W) p[(size_t)blockIdx.z * stride_e + (size_t)blockIdx.y * pitch_e + x] = (int16_t)value;
+}
+
+// defined in post.hip
+int launch_median3(const int16_t* src, size_t src_pitch_e, size_t src_stride_e, int16_t* dst,
+                   size_t dst_pitch_e, size_t dst_stride_e, int w, int h, int batch, hipStream_t st);
+int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, int new_val, int max_size,
+                   int max_diff, void* ws, int batch, hipStream_t st);
+size_t speckle_ws_bytes(int w, int h, int batch);
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+enum Stage { ST_PREP = 0, ST_HSUM, ST_VSUM, ST_SCAN, ST_WTA, ST_POST, ST_COUNT };
+static const char* kStageNames[ST_COUNT] = {"bt_prepare", "hsum", "vsum", "scan", "wta", "median_speckle"};
+
+}  // namespace camd
+
+struct camd_sgbm {
+    camd::Geom g;
+    camd_sgbm_params params;
+    int max_batch;
+    size_t vol_elems;     // per pair, int16 elements of one volume
+    size_t pk_elems;      // per pair, dwords of one packed-plane array
+    uint32_t *Lpk, *Rpk;
+    uint16_t *C, *S;      // S doubles as the hsum buffer before aggregation
+    int16_t* raw;         // [max_batch][H][W] disparity before median
+    void* speckle_ws;
+    int last_batch;
+    bool profiling;
+    hipEvent_t ev[camd::ST_COUNT + 1];
+    bool ev_ok;
+};
+
+namespace camd {
+
+static int normalise(const camd_sgbm_params* p, int width, int height, int cn, Geom* g)
+{
+    if (!p) { set_error("params is NULL"); return CAMD_ERR_BAD_ARG; }
+    if (width <= 0 || height <= 0 || (cn != 1 && cn != 3)) {
+        set_error("need width, height > 0 and 1 or 3 channels (got %d x %d x %d)", width, height, cn);
+        return CAMD_ERR_BAD_ARG;
+    }
+    if (p->numDisparities <= 0) { set_error("numDisparities must be > 0"); return CAMD_ERR_BAD_ARG; }
+    if (p->mode != CAMD_MODE_SGBM && p->mode != CAMD_MODE_HH) {
+        set_error("mode %d not implemented (MODE_SGBM=0, MODE_HH=1)", p->mode);
+        return CAMD_ERR_UNSUPPORTED;
+    }
+    memset(g, 0, sizeof(*g));
+    g->W = width; g->H = height; g->cn = cn;
+    g->minD = p->minDisparity; g->D = p->numDisparities;
+    int maxD = g->minD + g->D;
+    g->minX1 = maxD > 0 ? maxD : 0;
+    int maxX1 = width + (g->minD < 0 ? g->minD : 0);
+    g->W1 = maxX1 - g->minX1;
+    g->uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
+    g->d12 = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
+    g->P1 = p->P1 > 0 ? p->P1 : 2;
+    int P2 = p->P2 > 0 ? p->P2 : 5;
+    g->P2 = P2 > g->P1 + 1 ? P2 : g->P1 + 1;
+    int bs = p->blockSize > 0 ? p->blockSize : 5;
+    g->SW2 = bs / 2;
+    g->ftzero = (p->preFilterCap > 15 ? p->preFilterCap : 15) | 1;
+    g->mode = p->mode;
+    g->npaths = p->mode == CAMD_MODE_HH ? 8 : 5;
+    g->speckleWindowSize = p->speckleWindowSize;
+    g->speckleRange = p->speckleRange;
+    if (2 * g->SW2 + 1 > HSUM_RING) {
+        set_error("blockSize %d > %d not implemented", bs, HSUM_RING - 1);
+        return CAMD_ERR_UNSUPPORTED;
+    }
+    if (g->P2 > 16000 || g->ftzero > 127) {
+        set_error("P2 = %d / preFilterCap = %d outside the int16 regime the kernels implement", g->P2,
+                  p->preFilterCap);
+        return CAMD_ERR_UNSUPPORTED;
+    }
+    if (g->D > 512) { set_error("numDisparities %d > 512 not implemented", g->D); return CAMD_ERR_UNSUPPORTED; }
+    if (g->D > 64) { g->lanes = 16; g->nv = (g->D + 127) / 128; }
+    else if (g->D > 32) { g->lanes = 8; g->nv = 1; }
+    else if (g->D > 16) { g->lanes = 4; g->nv = 1; }
+    else { g->lanes = 2; g->nv = 1; }
+    g->Dp = g->lanes * 8 * g->nv;
+    return CAMD_OK;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <bool FIRST>
+static int launch_scan(const camd_sgbm* h, int dx, int dy, int batch, hipStream_t st)
+{
+    const Geom& g = h->g;
+    int nlines = dy == 0 ? g.H : (dx == 0 ? g.W1 : g.W1 + g.H - 1);
+    dim3 grid(div_up((long long)nlines * g.lanes, 256), batch);
+    const bool pad = g.Dp != g.D;
+#define CAMD_SCAN(LN, NVV)                                                                            \
+    do {                                                                                              \
+        if (pad) hipLaunchKernelGGL((k_scan<LN, NVV, FIRST, true>), grid, dim3(256), 0, st, h->C, h->S, g, \
+                                    dx, dy, nlines, h->vol_elems);                                    \
+        else hipLaunchKernelGGL((k_scan<LN, NVV, FIRST, false>), grid, dim3(256), 0, st, h->C, h->S, g, \
+                                dx, dy, nlines, h->vol_elems);                                        \
+    } while (0)
+    if (g.lanes == 2) CAMD_SCAN(2, 1);
+    else if (g.lanes == 4) CAMD_SCAN(4, 1);
+    else if (g.lanes == 8) CAMD_SCAN(8, 1);
+    else if (g.nv == 1) CAMD_SCAN(16, 1);
+    else if (g.nv == 2) CAMD_SCAN(16, 2);
+    else if (g.nv == 3) CAMD_SCAN(16, 3);
+    else CAMD_SCAN(16, 4);
+#undef CAMD_SCAN
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
+static int launch_wta(const camd_sgbm* h, int16_t* disp, size_t pitch_e, size_t stride_e, int batch,
+                      hipStream_t st)
+{
+    const Geom& g = h->g;
+    dim3 grid(g.H, batch);
+    size_t lds = (size_t)g.W * 6;
+    lds = align_up(lds, 16);
+#define CAMD_WTA(LN, NVV)                                                                           \
+    hipLaunchKernelGGL((k_wta<LN, NVV>), grid, dim3(256), lds, st, h->S, disp, pitch_e, stride_e, g, \
+                       h->vol_elems)
+    if (g.lanes == 2) CAMD_WTA(2, 1);
+    else if (g.lanes == 4) CAMD_WTA(4, 1);
+    else if (g.lanes == 8) CAMD_WTA(8, 1);
+    else if (g.nv == 1) CAMD_WTA(16, 1);
+    else if (g.nv == 2) CAMD_WTA(16, 2);
+    else if (g.nv == 3) CAMD_WTA(16, 3);
+    else CAMD_WTA(16, 4);
+#undef CAMD_WTA
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
+}  // namespace camd
+
+using namespace camd;
+
+extern "C" {
+
+size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int height, int channels,
+                                 int max_batch)
+{
+    Geom g;
+    if (normalise(p, width, height, channels, &g) != CAMD_OK || max_batch <= 0) return 0;
+    size_t w1 = g.W1 > 0 ? (size_t)g.W1 : 0;
+    size_t vol = align_up((size_t)height * w1 * g.Dp * 2, 256);
+    size_t pk = align_up((size_t)height * width * channels * 3 * 4, 256);
+    size_t raw = align_up((size_t)height * width * 2, 256);
+    return (size_t)max_batch * (2 * vol + 2 * pk + raw) + speckle_ws_bytes(width, height, max_batch);
+}
+
+int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int channels, int max_batch,
+                     camd_sgbm** out)
+{
+    if (!out) { set_error("out is NULL"); return CAMD_ERR_BAD_ARG; }
+    *out = nullptr;
+    Geom g;
+    int rc = normalise(p, width, height, channels, &g);
+    if (rc != CAMD_OK) return rc;
+    if (max_batch <= 0) { set_error("max_batch must be > 0"); return CAMD_ERR_BAD_ARG; }
+    rc = camd_device_ok();
+    if (rc != CAMD_OK) return rc;
+    camd_sgbm* h = new (std::nothrow) camd_sgbm();
+    if (!h) { set_error("out of host memory"); return CAMD_ERR_NOMEM; }
+    memset(h, 0, sizeof(*h));
+    h->g = g;
+    h->params = *p;
+    h->max_batch = max_batch;
+    size_t w1 = g.W1 > 0 ? (size_t)g.W1 : 0;
+    h->vol_elems = align_up((size_t)height * w1 * g.Dp * 2, 256) / 2;
+    h->pk_elems = align_up((size_t)height * width * channels * 3 * 4, 256) / 4;
+    size_t raw_e = align_up((size_t)height * width * 2, 256) / 2;
+    hipError_t e = hipSuccess;
+    if (w1 > 0) {
+        if (e == hipSuccess) e = hipMalloc((void**)&h->C, (size_t)max_batch * h->vol_elems * 2);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->S, (size_t)max_batch * h->vol_elems * 2);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->Lpk, (size_t)max_batch * h->pk_elems * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->Rpk, (size_t)max_batch * h->pk_elems * 4);
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&h->raw, (size_t)max_batch * raw_e * 2);
+    size_t sws = speckle_ws_bytes(width, height, max_batch);
+    if (e == hipSuccess && g.speckleWindowSize > 0) e = hipMalloc(&h->speckle_ws, sws);
+    if (e != hipSuccess) {
+        set_error("workspace allocation failed: %s", hipGetErrorString(e));
+        camd_sgbm_destroy(h);
+        return e == hipErrorOutOfMemory ? CAMD_ERR_NOMEM : CAMD_ERR_HIP;
+    }
+    *out = h;
+    return CAMD_OK;
+}
+
+int camd_sgbm_destroy(camd_sgbm* h)
+{
+    if (!h) return CAMD_OK;
+    if (h->ev_ok)
+        for (int i = 0; i <= ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
+    (void)hipFree(h->C); (void)hipFree(h->S); (void)hipFree(h->Lpk); (void)hipFree(h->Rpk);
+    (void)hipFree(h->raw); (void)hipFree(h->speckle_ws);
+    delete h;
+    return CAMD_OK;
+}
+
+int camd_sgbm_query(const camd_sgbm* h, int* width1, int* D, int* Dp, int* minX1)
+{
+    if (!h) { set_error("handle is NULL"); return CAMD_ERR_BAD_ARG; }
+    if (width1) *width1 = h->g.W1;
+    if (D) *D = h->g.D;
+    if (Dp) *Dp = h->g.Dp;
+    if (minX1) *minX1 = h->g.minX1;
+    return CAMD_OK;
+}
+
+int camd_sgbm_set_profiling(camd_sgbm* h, int enable)
+{
+    if (!h) { set_error("handle is NULL"); return CAMD_ERR_BAD_ARG; }
+    if (enable && !h->ev_ok) {
+        for (int i = 0; i <= ST_COUNT; i++) CAMD_HIP(hipEventCreate(&h->ev[i]));
+        h->ev_ok = true;
+    }
+    h->profiling = enable != 0;
+    return CAMD_OK;
+}
+int camd_sgbm_num_stages(void) { return ST_COUNT; }
+const char* camd_sgbm_stage_name(int i) { return i >= 0 && i < ST_COUNT ? kStageNames[i] : ""; }
+int camd_sgbm_get_profile(camd_sgbm* h, float* ms, int n)
+{
+    if (!h || !ms) { set_error("NULL argument"); return CAMD_ERR_BAD_ARG; }
+    if (!h->ev_ok || !h->profiling) { set_error("profiling not enabled"); return CAMD_ERR_BAD_ARG; }
+    CAMD_HIP(hipEventSynchronize(h->ev[ST_COUNT]));
+    for (int i = 0; i < n && i < ST_COUNT; i++) CAMD_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    return CAMD_OK;
+}
+
+int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, size_t pitch,
+                      size_t image_stride, int16_t* disp, size_t disp_pitch, size_t disp_stride,
+                      int batch, void* stream)
+{
+    if (!h || !left || !right || !disp) { set_error("NULL argument"); return CAMD_ERR_BAD_ARG; }
+    const Geom& g = h->g;
+    if (batch <= 0 || batch > h->max_batch) {
+        set_error("batch %d outside [1, max_batch=%d]", batch, h->max_batch);
+        return CAMD_ERR_BAD_ARG;
+    }
+    if (pitch < (size_t)g.W * g.cn || disp_pitch < (size_t)g.W * 2 || (disp_pitch & 1) || (disp_stride & 1)) {
+        set_error("pitch too small or odd disparity pitch");
+        return CAMD_ERR_BAD_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t dpe = disp_pitch / 2, dse = disp_stride / 2;
+    const bool prof = h->profiling && h->ev_ok;
+#define MARK(i) do { if (prof) CAMD_HIP(hipEventRecord(h->ev[i], st)); } while (0)
+    h->last_batch = batch;
+    const size_t raw_stride = align_up((size_t)g.H * g.W * 2, 256) / 2;
+
+    if (g.W1 <= 0) {
+        // minX1 >= maxX1: everything is INVALID_DISP_SCALED; the median of a constant is the constant
+        hipLaunchKernelGGL(k_fill_s16, dim3(div_up(g.W, 256), g.H, batch), dim3(256), 0, st, disp, dpe, dse,
+                           g.W, g.H, (g.minD - 1) * 16);
+        CAMD_LAUNCH_CHECK();
+        return CAMD_OK;
+    }
+
+    MARK(ST_PREP);
+    hipLaunchKernelGGL(k_bt_prepare, dim3(div_up(g.W, 256), g.H, batch * 2), dim3(256), 0, st, left, right,
+                       pitch, image_stride, h->Lpk, h->Rpk, g.W, g.H, g.cn, g.ftzero);
+    CAMD_LAUNCH_CHECK();
+
+    MARK(ST_HSUM);
+    {
+        int nseg = div_up(g.W1, HSUM_SEG), ndblk = div_up(g.Dp, 64);
+        dim3 grid(div_up((long long)nseg * ndblk, HSUM_WAVES), g.H, batch);
+        if (g.cn == 1)
+            hipLaunchKernelGGL((k_hsum<1>), grid, dim3(64 * HSUM_WAVES), 0, st, h->Lpk, h->Rpk, h->S, g, nseg,
+                               ndblk, h->vol_elems);
+        else
+            hipLaunchKernelGGL((k_hsum<3>), grid, dim3(64 * HSUM_WAVES), 0, st, h->Lpk, h->Rpk, h->S, g, nseg,
+                               ndblk, h->vol_elems);
+        CAMD_LAUNCH_CHECK();
+    }
+
+    MARK(ST_VSUM);
+    {
+        size_t rowv = (size_t)g.W1 * (g.Dp / 8);
+        hipLaunchKernelGGL(k_vsum, dim3(div_up((long long)rowv, 256), g.H, batch), dim3(256), 0, st,
+                           reinterpret_cast<const uint4*>(h->S), reinterpret_cast<uint4*>(h->C), g,
+                           h->vol_elems / 8);
+        CAMD_LAUNCH_CHECK();
+    }
+
+    MARK(ST_SCAN);
+    {
+        static const int dirs[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1}};
+        for (int i = 0; i < g.npaths; i++) {
+            int rc = i == 0 ? launch_scan<true>(h, dirs[i][0], dirs[i][1], batch, st)
+                            : launch_scan<false>(h, dirs[i][0], dirs[i][1], batch, st);
+            if (rc != CAMD_OK) return rc;
+        }
+    }
+
+    MARK(ST_WTA);
+    {
+        int rc = launch_wta(h, h->raw, (size_t)g.W, raw_stride, batch, st);
+        if (rc != CAMD_OK) return rc;
+    }
+
+    MARK(ST_POST);
+    {
+        int rc = launch_median3(h->raw, g.W, raw_stride, disp, dpe, dse, g.W, g.H, batch, st);
+        if (rc != CAMD_OK) return rc;
+        if (g.speckleWindowSize > 0) {
+            rc = launch_speckle(disp, dpe, dse, g.W, g.H, (g.minD - 1) * 16, g.speckleWindowSize,
+                                16 * g.speckleRange, h->speckle_ws, batch, st);
+            if (rc != CAMD_OK) return rc;
+        }
+    }
+    MARK(ST_COUNT);
+#undef MARK
+    return CAMD_OK;
+}
+
+int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* stream)
+{
+    if (!h || !dst) { set_error("NULL argument"); return CAMD_ERR_BAD_ARG; }
+    if (index < 0 || index >= h->max_batch) { set_error("index out of range"); return CAMD_ERR_BAD_ARG; }
+    const Geom& g = h->g;
+    hipStream_t st = (hipStream_t)stream;
+    if (which == 0 || which == 1) {
+        if (g.W1 <= 0) return CAMD_OK;
+        const uint16_t* src = (which == 0 ? h->C : h->S) + (size_t)index * h->vol_elems;
+        CAMD_HIP(hipMemcpyAsync(dst, src, (size_t)g.H * g.W1 * g.Dp * 2, hipMemcpyDeviceToDevice, st));
+    } else if (which == 2) {
+        const size_t raw_stride = align_up((size_t)g.H * g.W * 2, 256) / 2;
+        CAMD_HIP(hipMemcpyAsync(dst, h->raw + (size_t)index * raw_stride, (size_t)g.H * g.W * 2,
+                                hipMemcpyDeviceToDevice, st));
+    } else {
+        set_error("which must be 0 (C), 1 (S) or 2 (raw disparity)");
+        return CAMD_ERR_BAD_ARG;
+    }
+    return CAMD_OK;
+}
+
+}  // extern "C"

@@ -83,3 +83,33 @@ def scene_pair(seed=7, W=1280, H=720, cn=3):
     img1 = base[:, 64:].copy()
     img2 = base[:, 40:40 + W].copy()
     return img1, img2
+
+
+def rectified_batch_torch(seed, n, H=1080, W=1920, D=128, cn=1, device="cuda"):
+    """n distinct rectified pairs generated on the GPU (bench input; no host loop).
+
+    Same family as ``rectified_pair`` -- box-smoothed random texture, sinusoidal disparity field in
+    [D/8, 7D/8] whose phase differs per pair -- but built by a gather (left[x] = right[x - g(x)]) so it
+    vectorises.  Returns uint8 tensors (n, H, W) for cn == 1, (n, H, W, cn) otherwise.
+    """
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    right = torch.randint(0, 256, (n, H + 2, W + 2, cn), generator=gen, device=device, dtype=torch.int32)
+    acc = torch.zeros((n, H, W, cn), dtype=torch.int32, device=device)
+    for dy in range(3):
+        for dx in range(3):
+            acc += right[:, dy:dy + H, dx:dx + W]
+    right = (acc // 9)
+    yy = torch.arange(H, device=device, dtype=torch.float32)[None, :, None]
+    xx = torch.arange(W, device=device, dtype=torch.float32)[None, None, :]
+    ph = torch.arange(n, device=device, dtype=torch.float32)[:, None, None] * 0.37
+    g = torch.round(D / 8 + (3 * D / 4) * (0.5 + 0.5 * torch.sin(2 * np.pi * xx / W + ph) * torch.cos(2 * np.pi * yy / H)))
+    src = (xx - g).long().clamp_(0, W - 1).expand(n, H, W)
+    left = torch.gather(right, 2, src[..., None].expand(n, H, W, cn))
+    noise = torch.randint(-2, 3, left.shape, generator=gen, device=device, dtype=torch.int32)
+    left = (left + noise).clamp_(0, 255).to(torch.uint8)
+    right = right.to(torch.uint8)
+    if cn == 1:
+        return left[..., 0].contiguous(), right[..., 0].contiguous()
+    return left.contiguous(), right.contiguous()

@@ -1,0 +1,134 @@
+/*
+ * calibrating_amd.h -- C ABI of libcalibrating_amd.so: the MI355X (gfx950) stereo-depth hot path of
+ * DIYer22/calibrating, `Stereo.get_depth(img1, img2)`.
+ *
+ * Every entry point replaces one native (cv2 / NumPy) call the reference makes on that path; the
+ * file:line after "replaces" points into /root/reference/calibrating/.  All image / volume pointers
+ * are DEVICE pointers unless the name ends in `_host`; `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  Launches are asynchronous on `stream`; nothing here calls
+ * hipDeviceSynchronize.  Return value: 0 on success, a negative camd_status otherwise;
+ * camd_last_error() then holds a message (thread-local).
+ *
+ * Handles are not thread-safe: use one handle per host thread / stream.
+ */
+#ifndef CALIBRATING_AMD_H
+#define CALIBRATING_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum camd_status {
+    CAMD_OK = 0,
+    CAMD_ERR_BAD_ARG = -1,     /* size/type mismatch (cv2 raises cv2.error there) */
+    CAMD_ERR_UNSUPPORTED = -2, /* parameter outside what the kernels implement */
+    CAMD_ERR_NO_DEVICE = -3,   /* no HIP device / not gfx950 */
+    CAMD_ERR_HIP = -4,         /* a HIP runtime call failed */
+    CAMD_ERR_NOMEM = -5
+} camd_status;
+
+const char* camd_last_error(void);
+int camd_version(void);
+/* 0 when a gfx950 device is usable by this process, CAMD_ERR_NO_DEVICE otherwise */
+int camd_device_ok(void);
+
+/* ---- SGBM ------------------------------------------------------------------------------------
+ * replaces cv2.StereoSGBM_create(...) and .compute(left, right):
+ *   stereo_matching.py:48-58 (create; field order = keyword order there, plus preFilterCap, mode)
+ *   stereo_matching.py:63    (compute), stereo_matching.py:64 (getMinDisparity)                */
+typedef struct camd_sgbm_params {
+    int minDisparity;
+    int numDisparities;
+    int blockSize;
+    int P1;
+    int P2;
+    int disp12MaxDiff;
+    int preFilterCap;
+    int uniquenessRatio;
+    int speckleWindowSize;
+    int speckleRange;
+    int mode; /* CAMD_MODE_SGBM = 0 (5 paths; the reference's call), CAMD_MODE_HH = 1 (8 paths) */
+} camd_sgbm_params;
+enum { CAMD_MODE_SGBM = 0, CAMD_MODE_HH = 1 };
+
+typedef struct camd_sgbm camd_sgbm;
+
+/* Workspace (device) bytes a handle for these sizes allocates. 0 on bad arguments. */
+size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int height, int channels,
+                                 int max_batch);
+/* Allocates the per-pair workspace for `max_batch` pairs of width x height x channels (1 or 3) u8. */
+int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int channels, int max_batch,
+                     camd_sgbm** out);
+int camd_sgbm_destroy(camd_sgbm* h);
+/* left/right: u8 [batch][height][width*channels] with row pitch `pitch` bytes and `image_stride`
+ * bytes between consecutive pairs; disp: int16 [batch][height][width] (disparity * 16, cv2's
+ * fixed point) with `disp_pitch` / `disp_stride` bytes.  batch <= max_batch.                    */
+int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, size_t pitch,
+                      size_t image_stride, int16_t* disp, size_t disp_pitch, size_t disp_stride,
+                      int batch, void* stream);
+/* geometry of the internal cost volume: x in cost coordinates [0,width1), d in [0,D), padded to Dp */
+int camd_sgbm_query(const camd_sgbm* h, int* width1, int* D, int* Dp, int* minX1);
+/* stage-wise parity hooks: copy the volume of pair `index` of the last compute, [height][width1][Dp]
+ * int16, to dst (device).  which: 0 = matching cost C (incl. +P2), 1 = aggregated S,
+ * 2 = raw disparity before median/speckle as int16 [height][width] */
+int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* stream);
+/* per-stage GPU time of the last compute, measured with hipEvents on `stream` (enable first).
+ * stage names: camd_sgbm_stage_name(i), i in [0, camd_sgbm_num_stages()) */
+int camd_sgbm_set_profiling(camd_sgbm* h, int enable);
+int camd_sgbm_num_stages(void);
+const char* camd_sgbm_stage_name(int i);
+int camd_sgbm_get_profile(camd_sgbm* h, float* ms_per_stage, int n);
+
+/* replaces cv2.medianBlur(disp, disp, 3) and cv2.filterSpeckles inside StereoSGBM.compute; exported
+ * for stage-wise parity.  src/dst int16 [batch][h][w] contiguous; dst != src.                      */
+int camd_median3_s16(const int16_t* src, int16_t* dst, int w, int h, int batch, void* stream);
+/* in place; labels_ws: device scratch of camd_speckle_workspace_bytes(w,h,batch) */
+size_t camd_speckle_workspace_bytes(int w, int h, int batch);
+int camd_filter_speckles_s16(int16_t* img, int w, int h, int new_val, int max_speckle_size,
+                             int max_diff, void* labels_ws, int batch, void* stream);
+
+/* ---- remaps ----------------------------------------------------------------------------------
+ * replaces cv2.remap(img, mapx, mapy, interp) on u8 HWC with CV_32FC1 maps, BORDER_CONSTANT 0:
+ *   stereo_camera.py:217-228 (INTER_LANCZOS4, both cameras)
+ * x_shift implements stereo_camera.py:230-240 (translation_rectify_img): dst[:, x] takes the remap
+ * result of column x - x_shift, vacated columns are 0.                                          */
+enum { CAMD_INTER_NEAREST = 0, CAMD_INTER_LINEAR = 1, CAMD_INTER_LANCZOS4 = 4 };
+int camd_remap_u8(const uint8_t* src, int sw, int sh, int cn, size_t src_pitch, size_t src_stride,
+                  const float* mapx, const float* mapy, uint8_t* dst, int dw, int dh,
+                  size_t dst_pitch, size_t dst_stride, int interp, int x_shift, int batch,
+                  void* stream);
+/* replaces cv2.undistort(img1, K, D) (stereo_camera.py:430-431): bilinear fixed-point remap through
+ * the CV_16SC2 + CV_16UC1 maps cv2.undistort builds internally (camd_undistort_maps_host).       */
+int camd_remap_fixed_bilinear_u8(const uint8_t* src, int sw, int sh, int cn, size_t src_pitch,
+                                 size_t src_stride, const int16_t* mapxy, const uint16_t* mapa,
+                                 uint8_t* dst, int dw, int dh, size_t dst_pitch, size_t dst_stride,
+                                 int batch, void* stream);
+/* host, init time: the stripe-wise fixed-point maps of cv2.undistort (2*w*h int16 + w*h uint16) */
+int camd_undistort_maps_host(const double K[9], const double* dist, int ndist, int w, int h,
+                             int16_t* mapxy_host, uint16_t* mapa_host);
+/* host, init time: the 32x32-phase int16 weight tables cv2.remap uses (1024*64 / 1024*4 entries) */
+int camd_lanczos4_table_host(int16_t* tab_host);
+int camd_bilinear_table_host(int16_t* tab_host);
+
+/* ---- depth -----------------------------------------------------------------------------------
+ * replaces stereo_matching.py:63-69 (int16 -> f32, clip, < minD*16 -> 0, /16, identity resize),
+ * stereo_camera.py:510-512 (+= min_disparity, * rectify_valid_mask1) and
+ * stereo_camera.py:408-413 (Stereo.disparity_to_depth) in one pass.
+ * valid_mask: u8 [h][w] shared by the batch; disparity: f32, depth: f64 (NumPy >= 2 dtype).      */
+int camd_disp_to_depth(const int16_t* disp16, const uint8_t* valid_mask, int w, int h,
+                       int sgbm_min_disparity, int add_min_disparity, int translate,
+                       double baseline_fx, double max_depth, float* disparity, double* depth,
+                       int batch, void* stream);
+/* replaces utils.rotate_depth_by_remap (utils.py:192-199) as called by Stereo.unrectify_depth
+ * (stereo_camera.py:415-428): z' = M20*(u*z) + M21*(v*z) + M22*z, then INTER_NEAREST remap.      */
+int camd_unrectify_depth(const double* depth, int w, int h, const double M_row2_host[3],
+                         const float* mapx, const float* mapy, double* out, int ow, int oh,
+                         int batch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

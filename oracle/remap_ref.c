@@ -76,9 +76,15 @@ static void init_inter_tab_2d(int ksize, int16_t* itab)
         else
             interpolate_linear(i * scale, tab1d + i * 2);
     }
-    /* OpenCV scans k1,k2 in [ksize/2, ksize/2+2); for ksize 2 that window leaves the 2x2 table,
-       but the bilinear weights always sum to exactly 32768 so the correction never fires */
-    int glo = ksize == 8 ? oracle_sw_lanczos_group() : 0;
+    /* OpenCV scans k1,k2 in [ksize/2, ksize/2+2) relative to the entry; for ksize 2 that window
+       reaches past the 2x2 entry into the following entries of the (static, zero-initialised) table,
+       which are not filled yet when the entry is processed.  Restated literally: candidates are read
+       from the whole table (zero where not yet written, skipped past its end).  It only fires at
+       phase (0,0), where saturate_cast<short>(32768) = 32767 leaves the sum one short. */
+    int glo = ksize == 8 ? oracle_sw_lanczos_group() : ksize / 2;
+    int16_t* const tab0 = itab;
+    const ptrdiff_t total = (ptrdiff_t)INTER_TAB_SIZE2 * ksize * ksize;
+    memset(itab, 0, (size_t)total * sizeof(int16_t));
     for (int i = 0; i < INTER_TAB_SIZE; i++)
         for (int j = 0; j < INTER_TAB_SIZE; j++, itab += ksize * ksize) {
             int isum = 0;
@@ -92,8 +98,10 @@ static void init_inter_tab_2d(int ksize, int16_t* itab)
             if (isum != INTER_REMAP_COEF_SCALE) {
                 int diff = isum - INTER_REMAP_COEF_SCALE;
                 int Mk1 = glo, Mk2 = glo, mk1 = glo, mk2 = glo;
+                const ptrdiff_t room = total - (itab - tab0);
                 for (int k1 = glo; k1 < glo + 2; k1++)
                     for (int k2 = glo; k2 < glo + 2; k2++) {
+                        if (k1 * ksize + k2 >= room) continue;
                         if (itab[k1 * ksize + k2] < itab[mk1 * ksize + mk2])
                             mk1 = k1, mk2 = k2;
                         else if (itab[k1 * ksize + k2] > itab[Mk1 * ksize + Mk2])

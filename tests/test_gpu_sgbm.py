@@ -1,0 +1,165 @@
+"""GPU parity of the HIP SGBM path against the CPU oracle, through the C ABI (-m gpu).
+
+Bar: bit-exact int16 disparity (max |disp - oracle| == 0), stage by stage (cost volume C,
+aggregated volume S, raw disparity, final disparity) on identical inputs.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from calibrating_amd import StereoSGBM_create, synthetic  # noqa: E402
+
+
+def _params(cn, D, bs, minD=0, mode=0, **kw):
+    p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=8 * cn * bs * bs, P2=32 * cn * bs * bs,
+             disp12MaxDiff=1, uniquenessRatio=10, speckleWindowSize=0, speckleRange=0, mode=mode)
+    p.update(kw)
+    return p
+
+
+def _check_stages(oracle, left, right, p, stages=True):
+    m = StereoSGBM_create(**p)
+    got = m.compute(left, right)
+    ref = oracle.sgbm_compute(left, right, **p)
+    if stages and m.geometry()["width1"] > 0:
+        C = m.debug_volume("C").cpu().numpy()
+        Cr = oracle.sgbm_cost_volume(left, right, **p)
+        assert np.array_equal(C, Cr), "cost volume differs: max |d| = %d at %s" % (
+            np.abs(C.astype(int) - Cr).max(), np.argwhere(C != Cr)[:5].tolist())
+        S = m.debug_volume("S").cpu().numpy()
+        Sr = oracle.sgbm_aggregated(left, right, **p)
+        assert np.array_equal(S, Sr), "aggregated volume differs: max |d| = %d at %s" % (
+            np.abs(S.astype(int) - Sr).max(), np.argwhere(S != Sr)[:5].tolist())
+        raw = m.debug_volume("raw").cpu().numpy()
+        rr = oracle.sgbm_compute(left, right, raw=True, **p)
+        assert np.array_equal(raw, rr), "raw disparity differs at %s" % np.argwhere(raw != rr)[:5].tolist()
+    assert got.dtype == np.int16 and got.shape == ref.shape
+    assert np.array_equal(got, ref), "disparity differs: %d px, max |d| = %d" % (
+        (got != ref).sum(), np.abs(got.astype(int) - ref).max())
+    return got
+
+
+CASES = [
+    # H, W, D, cn, bs, minD, mode
+    (48, 200, 128, 1, 5, 0, 0),    # 16 lanes x 1 vector, reference's mode
+    (48, 200, 128, 3, 5, 0, 1),    # RGB, 8 paths
+    (40, 330, 256, 1, 5, 0, 0),    # D = 256 (4K config): 2 vectors per lane
+    (40, 330, 218, 3, 11, 2, 0),   # the reference's hard-coded matcher: D = 218 (padded), block 11, minD 2
+    (37, 150, 64, 3, 5, 0, 0),     # 8-lane groups (VGA config)
+    (33, 97, 32, 1, 3, 0, 1),      # 4-lane groups
+    (31, 90, 16, 1, 3, 0, 0),      # 2-lane groups
+    (30, 120, 48, 1, 7, -7, 1),    # negative minDisparity, padded D
+    (25, 140, 100, 1, 9, 3, 0),    # D not a multiple of 8
+    (20, 64, 40, 3, 5, 5, 1),
+]
+
+
+@pytest.mark.parametrize("H,W,D,cn,bs,minD,mode", CASES)
+def test_sgbm_stagewise_bit_exact(oracle, H, W, D, cn, bs, minD, mode):
+    left, right = synthetic.rectified_pair(seed=11 + D, H=H, W=W, D=max(D, 8), cn=cn)
+    _check_stages(oracle, left, right, _params(cn, D, bs, minD, mode))
+
+
+def test_sgbm_random_noise_images(oracle):
+    """Uncorrelated noise: exercises uniqueness rejections, LR-check failures, ties."""
+    rng = np.random.default_rng(3)
+    left = rng.integers(0, 256, (40, 180, 3), dtype=np.uint8)
+    right = rng.integers(0, 256, (40, 180, 3), dtype=np.uint8)
+    for mode in (0, 1):
+        _check_stages(oracle, left, right, _params(3, 64, 3, 0, mode, uniquenessRatio=0, disp12MaxDiff=2))
+
+
+def test_sgbm_flat_images_ties(oracle):
+    """Constant images: every cost ties; bestDisp must be the smallest d, disp2 ties keep larger x."""
+    left = np.full((24, 100), 77, np.uint8)
+    right = np.full((24, 100), 77, np.uint8)
+    got = _check_stages(oracle, left, right, _params(1, 32, 5, 0, 0))
+    assert (got[:, :32] == -16).all()
+
+
+def test_sgbm_default_params_and_speckle(oracle):
+    left, right = synthetic.rectified_pair(seed=5, H=60, W=320, D=64, cn=3)
+    # cv2.StereoSGBM_create() defaults (P1 = P2 = 0 -> 2 / 5, uniqueness 0, disp12MaxDiff 0 -> 1)
+    _check_stages(oracle, left, right, dict(numDisparities=16, blockSize=3))
+    # speckle filter on
+    p = _params(3, 64, 5, 0, 0, speckleWindowSize=100, speckleRange=2)
+    _check_stages(oracle, left, right, p, stages=False)
+    p = _params(3, 64, 5, 1, 1, speckleWindowSize=30, speckleRange=1, uniquenessRatio=5)
+    _check_stages(oracle, left, right, p, stages=False)
+
+
+def test_sgbm_degenerate_width(oracle):
+    """numDisparities >= width: minX1 >= maxX1, everything is (minD-1)*16."""
+    left = np.zeros((10, 20), np.uint8)
+    got = StereoSGBM_create(numDisparities=32, blockSize=3).compute(left, left)
+    assert (got == -16).all()
+    assert np.array_equal(got, oracle.sgbm_compute(left, left, numDisparities=32, blockSize=3))
+
+
+def test_sgbm_batch_matches_single(oracle):
+    pairs = [synthetic.rectified_pair(seed=s, H=32, W=200, D=64, cn=1) for s in (1, 2, 3)]
+    L = np.stack([p[0] for p in pairs])
+    R = np.stack([p[1] for p in pairs])
+    p = _params(1, 64, 5)
+    m = StereoSGBM_create(**p)
+    got = m.compute(L, R)
+    assert got.shape == (3, 32, 200)
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.sgbm_compute(L[i], R[i], **p))
+    # torch tensors in -> torch tensor out, same values
+    gt = m.compute(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda())
+    assert gt.is_cuda and np.array_equal(gt.cpu().numpy(), got)
+
+
+def test_sgbm_known_answer_constant_shift():
+    """right = left shifted by d0 -> interior |disp16 - 16 d0| <= 8."""
+    rng = np.random.default_rng(0)
+    H, W, D, d0 = 40, 260, 128, 37
+    base = rng.integers(0, 256, (H, W + d0), dtype=np.uint8)
+    left, right = base[:, :W].copy(), base[:, d0:].copy()
+    for mode in (0, 1):
+        d = StereoSGBM_create(**_params(1, D, 5, 0, mode)).compute(left, right)
+        inner = d[4:-4, D + 8:-8 - d0].astype(int)
+        assert (np.abs(inner - 16 * d0) <= 8).all()
+        assert (d[:, :D] == -16).all()
+
+
+def test_sgbm_error_behaviour():
+    m = StereoSGBM_create(numDisparities=16, blockSize=3)
+    with pytest.raises(ValueError):
+        m.compute(np.zeros((8, 40), np.uint8), np.zeros((8, 41), np.uint8))
+    with pytest.raises(ValueError):
+        m.compute(np.zeros((8, 40), np.float32), np.zeros((8, 40), np.float32))
+    with pytest.raises(ValueError):
+        StereoSGBM_create(numDisparities=16, mode=2).compute(np.zeros((8, 40), np.uint8), np.zeros((8, 40), np.uint8))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sgbm_full_size_properties(mode):
+    """BASELINE config (1920x1080, D=128, blockSize 5) through size-independent properties:
+    determinism, invalid left band, batch invariance, and agreement with ground truth."""
+    D = 128
+    left, right = synthetic.rectified_pair(seed=1234, H=1080, W=1920, D=D, cn=1)
+    m = StereoSGBM_create(**_params(1, D, 5, 0, mode))
+    d1 = m.compute(left, right)
+    d2 = m.compute(np.stack([left, left]), np.stack([right, right]))
+    assert np.array_equal(d2[0], d1) and np.array_equal(d2[1], d1)
+    assert (d1[:, :D] == -16).all()
+    yy, xx = np.mgrid[:1080, :1920]
+    g = np.rint(D / 8 + (3 * D / 4) * (0.5 + 0.5 * np.sin(2 * np.pi * xx / 1920) * np.cos(2 * np.pi * yy / 1080)))
+    v = d1 >= 0
+    assert v.mean() > 0.7
+    assert (np.abs(d1[v] / 16.0 - g[v]) < 1).mean() > 0.9
+
+
+def test_sgbm_full_size_rows_vs_oracle(oracle):
+    """Full-width strip of the 1080p config against the oracle (the oracle finishes it in seconds)."""
+    D = 128
+    left, right = synthetic.rectified_pair(seed=1234, H=96, W=1920, D=D, cn=3)
+    for mode in (0, 1):
+        p = _params(3, D, 5, 0, mode)
+        got = StereoSGBM_create(**p).compute(left, right)
+        assert np.array_equal(got, oracle.sgbm_compute(left, right, **p))
