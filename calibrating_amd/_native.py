@@ -78,6 +78,9 @@ def lib():
             raise RuntimeError(
                 "calibrating_amd: %s is missing -- build the HIP extension first "
                 "(make -C calibrating_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        # torch first: it bundles its own libamdhip64.so.7; loading ours afterwards binds to that same
+        # HIP runtime instance, so device pointers and streams are shared with torch
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError here = header and library disagree

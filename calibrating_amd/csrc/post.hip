@@ -126,8 +126,10 @@ __global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, co
     if (x >= w) return;
     int16_t* p = img + (size_t)y * pitch + x;
     if (*p == new_val) return;
-    int r = parent[y * w + x];
-    r = parent[r];  // parent[] was flattened to roots by k_cc_count; one extra hop is harmless
+    // the forest is final here, but path halving in k_cc_count may have left parent[i] pointing at an
+    // inner node: walk to the root (read only)
+    int r = y * w + x;
+    for (int q = parent[r]; q != r; q = parent[r]) r = q;
     if (count[r] <= max_size) *p = (int16_t)new_val;
 }
 

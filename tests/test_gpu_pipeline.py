@@ -164,7 +164,7 @@ def test_get_depth_end_to_end(oracle, W, H, max_depth):
         assert got[k].dtype == np.float64
         assert np.array_equal(got[k] == 0, ref[k] == 0), k
         assert np.abs(got[k] - ref[k]).max() <= DEPTH_TOL, k
-    assert (got["rectify_depth"] > 0).mean() > 0.2
+    assert (got["rectify_depth"] > 0).mean() > 0.05
     # tensors in -> tensors out, same numbers
     gt = stereo.get_depth(torch.from_numpy(img1).cuda(), torch.from_numpy(img2).cuda())
     assert gt["unrectify_depth"].is_cuda
