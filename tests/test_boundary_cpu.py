@@ -1,0 +1,187 @@
+"""CPU tests of the drop-in boundary and the host logic (no GPU, no compute calls):
+the C-ABI library loads and exports every symbol include/calibrating_amd.h declares, the product fails
+loudly without a device, and the Python mirror of Stereo reproduces the reference's scalar logic and
+table construction (checked against the oracle and against geometric self-consistency)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import calibrating_amd as ca
+from calibrating_amd import _native, geometry, synthetic
+from calibrating_amd.parallel_pairs import owner_of, shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "calibrating_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(camd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    lib = _native.lib()
+    for s in syms:
+        assert hasattr(lib, s), "libcalibrating_amd.so does not export %s" % s
+    # and the binding table covers the whole header
+    assert set(syms) == set(_native.SIGNATURES)
+    assert lib.camd_version() >= 100
+    assert lib.camd_sgbm_num_stages() > 0 and lib.camd_sgbm_stage_name(0)
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert _native.lib().camd_device_ok() == _native.CAMD_ERR_NO_DEVICE
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ca.StereoSGBM_create(numDisparities=16).compute(np.zeros((8, 40), np.uint8), np.zeros((8, 40), np.uint8))
+    with pytest.raises(RuntimeError):
+        from calibrating_amd import imgproc
+        imgproc.remap(np.zeros((4, 4), np.uint8), np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
+
+
+def test_argument_validation_without_gpu():
+    import ctypes
+    lib = _native.lib()
+    p = _native.SgbmParams(numDisparities=128, blockSize=5, P1=200, P2=800)
+    # C2 workspace: two 495 MB volumes + planes + raw disparity per pair
+    ws = lib.camd_sgbm_workspace_bytes(ctypes.byref(p), 1920, 1080, 1, 1)
+    assert 2 * 1080 * 1792 * 128 * 2 < ws < 2.4 * 1080 * 1792 * 128 * 2
+    assert lib.camd_sgbm_workspace_bytes(ctypes.byref(p), 1920, 1080, 2, 1) == 0  # 2 channels: cv2 error too
+    bad = _native.SgbmParams(numDisparities=0)
+    h = ctypes.c_void_p()
+    assert lib.camd_sgbm_create(ctypes.byref(bad), 64, 64, 1, 1, ctypes.byref(h)) == _native.CAMD_ERR_BAD_ARG
+    assert "numDisparities" in _native.last_error()
+    m3 = _native.SgbmParams(numDisparities=16, mode=2)
+    assert lib.camd_sgbm_create(ctypes.byref(m3), 64, 64, 1, 1, ctypes.byref(h)) == _native.CAMD_ERR_UNSUPPORTED
+    # host-side table builders work without a device and match the oracle
+    tab = np.empty((1024, 64), np.int16)
+    assert lib.camd_lanczos4_table_host(tab.ctypes.data) == 0
+    import oracle
+    assert np.array_equal(tab, oracle.lanczos4_itab())
+    tb = np.empty((1024, 4), np.int16)
+    assert lib.camd_bilinear_table_host(tb.ctypes.data) == 0
+    assert np.array_equal(tb, oracle.bilinear_itab())
+
+
+def test_plugin_surface_matches_reference_names():
+    assert issubclass(ca.SemiGlobalBlockMatching, ca.MetaStereoMatching)
+    m = ca.SemiGlobalBlockMatching()
+    assert m.max_size == 1000 and m.cfg == {}
+    # the reference's hard-coded cv2.StereoSGBM_create arguments (stereo_matching.py:30-58)
+    assert m.stereo_sgbm.params == dict(minDisparity=2, numDisparities=218, blockSize=11, P1=968, P2=3872,
+                                        disp12MaxDiff=0, preFilterCap=0, uniquenessRatio=5,
+                                        speckleWindowSize=200, speckleRange=2, mode=0)
+    assert m.stereo_sgbm.getMinDisparity() == 2
+    with pytest.raises(NotImplementedError):
+        ca.MetaStereoMatching()(None, None)
+    with pytest.raises(TypeError):
+        ca.StereoSGBM_create(numDisparities=16, bogus=1)
+    m.stereo_sgbm.setNumDisparities(64)
+    assert m.stereo_sgbm.getNumDisparities() == 64
+
+
+def test_stereo_load_dump_roundtrip_and_scalars(tmp_path):
+    rig = synthetic.rig(320, 240)
+    s = ca.Stereo.load(rig)
+    assert s.xy == (320, 240) and s.undistort_rectify_map1[0].shape == (240, 320)
+    assert s.undistort_rectify_map1[0].dtype == np.float32 and s.rectify_valid_mask1.dtype == bool
+    assert abs(s.baseline - np.linalg.norm([0.12, 0.002, 0.001])) < 1e-12
+    path = str(tmp_path / "stereo.yaml")
+    s.dump(path)
+    s2 = ca.Stereo.load(path)
+    assert np.array_equal(s2.undistort_rectify_map2[1], s.undistort_rectify_map2[1])
+    s3 = ca.Stereo.load(s.dump())  # yaml string
+    assert np.allclose(s3.R1, s.R1)
+    # r (Rodrigues) and T (4x4) inputs (stereo_camera.py:287-291)
+    d = dict(rig)
+    d.pop("R")
+    d["r"] = [0.01, -0.02, 0.005]
+    assert np.allclose(ca.Stereo.load(d).R, s.R)
+    T = np.eye(4)
+    T[:3, :3] = s.R
+    T[:3, 3:] = s.t
+    d2 = {k: v for k, v in rig.items() if k not in ("R", "t")}
+    d2["T"] = T.tolist()
+    s4 = ca.Stereo.load(d2)
+    assert np.allclose(s4.R, s.R, atol=1e-9) and np.allclose(s4.t, s.t)
+    # set_stereo_matching scalar logic (stereo_camera.py:466-489), incl. quirk Q1 (cam1.K, not self.K)
+    s.set_stereo_matching(ca.SemiGlobalBlockMatching({}), max_depth=3.5)
+    assert s.translation_rectify_img is True and s.max_depth == 3.5
+    assert s.min_disparity == int(s.cam1.K[0, 0] * s.baseline / 3.5)
+    s.set_stereo_matching(ca.SemiGlobalBlockMatching({}))
+    assert s.translation_rectify_img is False and s.max_depth == 1000 and s.min_disparity == 0
+    s.set_stereo_matching(ca.SemiGlobalBlockMatching({}), max_depth=2.0, translation_rectify_img=False)
+    assert s.translation_rectify_img is False and s.min_disparity == int(s.cam1.K[0, 0] * s.baseline / 2.0)
+    # disparity_to_depth on the host (NumPy): reference edge cases (stereo_camera.py:408-413)
+    z = s.disparity_to_depth(np.array([[0.0, -1.0, 1e-9, 16.5]], np.float32))
+    bf = s.baseline * s.K[0, 0]
+    assert z.dtype == np.float64 and z[0, 0] == 0 and z[0, 1] == 0 and z[0, 2] == 0 and z[0, 3] == bf / 16.5
+    with pytest.raises(NotImplementedError):
+        ca.Stereo(s.cam1, s.cam2)  # extrinsic calibration is out of scope: needs R, t
+    s5 = ca.Stereo(s.cam1, s.cam2, R=s.R, t=s.t)
+    assert np.array_equal(s5.undistort_rectify_map1[0], s.undistort_rectify_map1[0])
+
+
+def test_rectification_is_self_consistent(oracle):
+    """R1 = R2 R; projecting a 3-D point through both rectified cameras gives equal rows;
+    maps equal the oracle's initUndistortRectifyMap; valid mask follows stereo_camera.py:167-176."""
+    s = ca.Stereo.load(synthetic.rig(640, 480))
+    assert np.allclose(s.R1, s.R2 @ s.R)
+    assert np.allclose(s.R1 @ s.R1.T, np.eye(3), atol=1e-12) and np.allclose(s.R2 @ s.R2.T, np.eye(3), atol=1e-12)
+    # cam2 = R cam1 + t (stereoCalibrate convention): rectified coords X1r = R1 X1, X2r = R2 X2
+    rng = np.random.default_rng(0)
+    X1 = rng.uniform([-1, -1, 1.5], [1, 1, 4], (50, 3))
+    X2 = X1 @ s.R.T + s.t.reshape(1, 3)
+    p1 = (X1 @ s.R1.T) @ s.K.T
+    p2 = (X2 @ s.R2.T) @ s.K.T
+    v1, v2 = p1[:, 1] / p1[:, 2], p2[:, 1] / p2[:, 2]
+    # epipolar lines are rows (residual ~3e-6 px comes from the reference's own eps = 1e-8 in
+    # rotate_shortest_of_two_vecs, utils.py:146)
+    assert np.abs(v1 - v2).max() < 1e-4
+    u1, u2 = p1[:, 0] / p1[:, 2], p2[:, 0] / p2[:, 2]
+    disp = u1 - u2
+    assert (disp > 0).all()                       # positive disparity, = baseline * fx / z
+    assert np.allclose(disp, s.baseline * s.K[0, 0] / (X1 @ s.R1.T)[:, 2], rtol=1e-6)
+    for cam, R, maps in ((s.cam1, s.R1, s.undistort_rectify_map1), (s.cam2, s.R2, s.undistort_rectify_map2)):
+        mx, my = oracle.init_undistort_rectify_map(cam.K, cam.D, R, s.K, s.xy)
+        assert np.array_equal(mx, maps[0]) and np.array_equal(my, maps[1])
+    mx, my = s.undistort_rectify_map1
+    W, H = s.cam1.xy
+    want = (-0.5 < mx) & (mx < W - 0.5) & (-0.5 < my) & (my < H - 0.5)
+    assert np.array_equal(s.rectify_valid_mask1, want)
+    # xy_target / K_target variants run and keep the principal ray near the image centre
+    s2 = ca.Stereo.load(dict(synthetic.rig(640, 480)))
+    s2.xy_target, s2.K_target = 0.5, 0.5
+    s2._get_undistort_rectify_map()
+    assert s2.xy == (320, 240) and abs(s2.K[0, 0] - 0.5 * s2.cam1.K[0, 0]) < 1e-9
+
+
+def test_geometry_helpers():
+    r = np.array([0.3, -0.2, 0.1])
+    R = geometry.rodrigues(r)
+    assert np.allclose(R @ R.T, np.eye(3)) and abs(np.linalg.det(R) - 1) < 1e-12
+    assert np.allclose(geometry.rodrigues(R).reshape(3), r)
+    assert np.allclose(geometry.rodrigues(np.zeros(3)), np.eye(3))
+    v1, v2 = np.array([-1.0, 0, 0]), np.array([-0.12, 0.002, -0.001])
+    Rs = geometry.rotate_shortest_of_two_vecs(v1, v2)
+    assert np.allclose(Rs @ v1, v2 / np.linalg.norm(v2), atol=1e-6)
+    assert np.allclose(geometry.project_vec_on_plane(np.array([1.0, 2, 3]), np.array([0, 0, 2.0])), [1, 2, 0])
+    m = np.array([[2.0, 1, 0], [0, 3, 1], [1, 0, 4]])
+    assert np.allclose(geometry.inv3(m) @ m, np.eye(3))
+
+
+def test_shard_ranges_cover_the_pair_list():
+    for n, g in ((512, 8), (10, 4), (7, 8), (64, 1)):
+        ranges = [shard_range(n, g, r) for r in range(g)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        for i in range(n):
+            r = owner_of(i, n, g)
+            assert ranges[r][0] <= i < ranges[r][1]
+    assert [shard_range(512, 8, r) for r in range(8)] == [(64 * r, 64 * r + 64) for r in range(8)]
