@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcalibrating_amd.so")
+# CAMD_LIB lets a measurement run load an experimental build of the same ABI (A/B kernel variants)
+LIB_PATH = os.environ.get("CAMD_LIB") or os.path.join(_HERE, "lib", "libcalibrating_amd.so")
 _lib = None
 
 c_void_p, c_int, c_size_t, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
@@ -47,6 +48,8 @@ SIGNATURES = {
                                   c_size_t, c_int, c_void_p]),
     "camd_sgbm_query": (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 4),
     "camd_sgbm_debug_copy": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "camd_sgbm_set_option": (c_int, [c_void_p, c_int, c_int]),
+    "camd_sgbm_status": (c_int, [c_void_p, c_void_p]),
     "camd_sgbm_set_profiling": (c_int, [c_void_p, c_int]),
     "camd_sgbm_num_stages": (c_int, []),
     "camd_sgbm_stage_name": (ctypes.c_char_p, [c_int]),

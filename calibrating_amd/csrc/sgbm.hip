@@ -468,6 +468,10 @@ __global__ void k_fill_s16(int16_t* p, size_t pitch_e, size_t stride_e, int W, i
     if (x < W) p[(size_t)blockIdx.z * stride_e + (size_t)blockIdx.y * pitch_e + x] = (int16_t)value;
 }
 
+}  // namespace camd
+#include "sgbm_band.hpp"
+namespace camd {
+
 // defined in post.hip
 int launch_median3(const int16_t* src, size_t src_pitch_e, size_t src_stride_e, int16_t* dst,
                    size_t dst_pitch_e, size_t dst_stride_e, int w, int h, int batch, hipStream_t st);
@@ -493,6 +497,16 @@ struct camd_sgbm {
     uint16_t *C, *S;      // S doubles as the hsum buffer before aggregation
     int16_t* raw;         // [max_batch][H][W] disparity before median
     void* speckle_ws;
+    // band-wavefront path (sgbm_band.hpp)
+    bool band_ok;         // geometry supported by k_band instantiations
+    int path;             // 0 = band passes (default when band_ok), 1 = one k_scan per direction
+    int keep_S;           // band path: also store S in the final pass (stage-wise parity hook)
+    int nbands, nchunks;
+    size_t erec_stride;
+    unsigned long long* E;
+    uint32_t *flags, *ticket, *err, *keys;
+    int16_t* d1;
+    uint32_t epoch;
     int last_batch;
     bool profiling;
     hipEvent_t ev[camd::ST_COUNT + 1];
@@ -600,6 +614,39 @@ static int launch_wta(const camd_sgbm* h, int16_t* disp, size_t pitch_e, size_t 
     return CAMD_OK;
 }
 
+// one band-wavefront pass over `batch` pairs: directions DIRS (bit0 H, bit1 V, bit2 Dg) of sweep (sx, sy)
+static int launch_band(camd_sgbm* h, int sx, int sy, int dirs, int mode, int batch, hipStream_t st)
+{
+    const Geom& g = h->g;
+    BandArgs a;
+    a.C = h->C; a.S = h->S; a.E = h->E; a.flags = h->flags; a.ticket = h->ticket; a.err = h->err;
+    a.keys = h->keys; a.d1 = h->d1; a.vol_stride = h->vol_elems; a.erec_stride = h->erec_stride;
+    a.sx = sx; a.sy = sy; a.nbands = h->nbands; a.nchunks = h->nchunks; a.npairs = batch;
+    a.epoch = ++h->epoch;
+    a.write_S = h->keep_S;
+    static const int nodep = getenv("CAMD_BAND_NODEP") ? atoi(getenv("CAMD_BAND_NODEP")) : 0;
+    a.nodep = nodep;
+    CAMD_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
+    dim3 grid(h->nbands * batch), block(BAND_BLOCK);
+#define CAMD_BAND(LN, NVV, DD, MM) hipLaunchKernelGGL((k_band<LN, NVV, DD, MM>), grid, block, 0, st, a, g)
+#define CAMD_BAND_SHAPE(DD, MM)                                   \
+    do {                                                          \
+        if (g.lanes == 16 && g.nv == 1) CAMD_BAND(16, 1, DD, MM); \
+        else if (g.lanes == 16) CAMD_BAND(16, 2, DD, MM);         \
+        else CAMD_BAND(8, 1, DD, MM);                             \
+    } while (0)
+    if (dirs == 7 && mode == 0) CAMD_BAND_SHAPE(7, 0);
+    else if (dirs == 7 && mode == 1) CAMD_BAND_SHAPE(7, 1);
+    else if (dirs == 5 && mode == 2) CAMD_BAND_SHAPE(5, 2);
+    else if (dirs == 4 && mode == 1) CAMD_BAND_SHAPE(4, 1);
+    else if (dirs == 4 && mode == 2) CAMD_BAND_SHAPE(4, 2);
+    else { set_error("band pass (%d, %d) not instantiated", dirs, mode); return CAMD_ERR_UNSUPPORTED; }
+#undef CAMD_BAND_SHAPE
+#undef CAMD_BAND
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
 }  // namespace camd
 
 using namespace camd;
@@ -649,6 +696,26 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     if (e == hipSuccess) e = hipMalloc((void**)&h->raw, (size_t)max_batch * raw_e * 2);
     size_t sws = speckle_ws_bytes(width, height, max_batch);
     if (e == hipSuccess && g.speckleWindowSize > 0) e = hipMalloc(&h->speckle_ws, sws);
+    // band-wavefront path: instantiated for 16 lanes x {1,2} vectors and 8 lanes x 1 vector
+    h->band_ok = w1 > 0 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    h->path = 0;
+    h->epoch = 0;
+    if (h->band_ok) {
+        const int R = BAND_THREADS / g.lanes;
+        h->nbands = div_up(height, R);
+        h->nchunks = div_up(g.W1, BAND_CHUNK);
+        h->erec_stride = (size_t)g.W1 * g.lanes * (4 * g.nv + 1);
+        size_t nflags = (size_t)max_batch * h->nbands * h->nchunks;
+        size_t npix = (size_t)max_batch * height * width;
+        if (e == hipSuccess) e = hipMalloc((void**)&h->E, (size_t)max_batch * h->nbands * h->erec_stride * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->flags, nflags * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->ticket, 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->keys, npix * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->d1, npix * 2);
+        if (e == hipSuccess) e = hipMemset(h->flags, 0, nflags * 4);
+        if (e == hipSuccess) e = hipMemset(h->ticket, 0, 8);
+        h->err = h->ticket + 1;
+    }
     if (e != hipSuccess) {
         set_error("workspace allocation failed: %s", hipGetErrorString(e));
         camd_sgbm_destroy(h);
@@ -665,6 +732,8 @@ int camd_sgbm_destroy(camd_sgbm* h)
         for (int i = 0; i <= ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
     (void)hipFree(h->C); (void)hipFree(h->S); (void)hipFree(h->Lpk); (void)hipFree(h->Rpk);
     (void)hipFree(h->raw); (void)hipFree(h->speckle_ws);
+    (void)hipFree(h->E); (void)hipFree(h->flags); (void)hipFree(h->ticket); (void)hipFree(h->keys);
+    (void)hipFree(h->d1);
     delete h;
     return CAMD_OK;
 }
@@ -676,6 +745,30 @@ int camd_sgbm_query(const camd_sgbm* h, int* width1, int* D, int* Dp, int* minX1
     if (D) *D = h->g.D;
     if (Dp) *Dp = h->g.Dp;
     if (minX1) *minX1 = h->g.minX1;
+    return CAMD_OK;
+}
+
+int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
+{
+    if (!h) { set_error("handle is NULL"); return CAMD_ERR_BAD_ARG; }
+    if (option == CAMD_OPT_PATH && (value == 0 || value == 1)) h->path = value;
+    else if (option == CAMD_OPT_KEEP_S) h->keep_S = value != 0;
+    else { set_error("unknown option %d / value %d", option, value); return CAMD_ERR_BAD_ARG; }
+    return CAMD_OK;
+}
+
+int camd_sgbm_status(camd_sgbm* h, void* stream)
+{
+    if (!h) { set_error("handle is NULL"); return CAMD_ERR_BAD_ARG; }
+    if (!h->err) return CAMD_OK;
+    uint32_t e = 0;
+    CAMD_HIP(hipMemcpyAsync(&e, h->err, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CAMD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (e) {
+        CAMD_HIP(hipMemsetAsync(h->err, 0, 4, (hipStream_t)stream));
+        set_error("a band-wavefront pass timed out waiting for its upstream band");
+        return CAMD_ERR_HIP;
+    }
     return CAMD_OK;
 }
 
@@ -756,8 +849,26 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         CAMD_LAUNCH_CHECK();
     }
 
+    const bool band = h->band_ok && h->path == 0;
     MARK(ST_SCAN);
-    {
+    if (band) {
+        // fused passes: every pass reads C once and touches S once for up to three directions
+        size_t npix = (size_t)batch * g.H * g.W;
+        hipLaunchKernelGGL(k_wta_init, dim3(div_up((long long)npix, 256)), dim3(256), 0, st, h->keys, h->d1, npix,
+                           (g.minD - 1) * 16);
+        CAMD_LAUNCH_CHECK();
+        int rc;
+        if (g.mode == CAMD_MODE_HH) {
+            rc = launch_band(h, +1, +1, 7, 0, batch, st);                 // ->  v  \.
+            if (rc == CAMD_OK) rc = launch_band(h, -1, -1, 7, 1, batch, st);  // <-  ^  \^
+            if (rc == CAMD_OK) rc = launch_band(h, -1, +1, 4, 1, batch, st);  // ./
+            if (rc == CAMD_OK) rc = launch_band(h, +1, -1, 4, 2, batch, st);  // /^ + WTA
+        } else {
+            rc = launch_band(h, +1, +1, 7, 0, batch, st);                 // ->  v  \.
+            if (rc == CAMD_OK) rc = launch_band(h, -1, +1, 5, 2, batch, st);  // <-  ./ + WTA
+        }
+        if (rc != CAMD_OK) return rc;
+    } else {
         static const int dirs[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1}};
         for (int i = 0; i < g.npaths; i++) {
             int rc = i == 0 ? launch_scan<true>(h, dirs[i][0], dirs[i][1], batch, st)
@@ -767,7 +878,11 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     }
 
     MARK(ST_WTA);
-    {
+    if (band) {
+        hipLaunchKernelGGL(k_lrcheck, dim3(div_up(g.W, 256), g.H, batch), dim3(256), 0, st, h->d1, h->keys, h->raw,
+                           (size_t)g.W, raw_stride, g);
+        CAMD_LAUNCH_CHECK();
+    } else {
         int rc = launch_wta(h, h->raw, (size_t)g.W, raw_stride, batch, st);
         if (rc != CAMD_OK) return rc;
     }

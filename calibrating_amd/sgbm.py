@@ -33,6 +33,22 @@ class StereoSGBM:
         self._handle = None
         self._key = None
         self.profiling = False
+        self._options = {}
+
+    def set_option(self, option, value):
+        """'path': 0 = fused band-wavefront passes (default), 1 = one line-scan launch per direction;
+        'keep_S': 1 = keep the aggregated volume for debug_volume('S') on the fused path."""
+        opt = {"path": 0, "keep_S": 1}[option]
+        self._options[opt] = int(value)
+        if self._handle is not None:
+            _native.check(_native.lib().camd_sgbm_set_option(self._handle, opt, int(value)))
+        return self
+
+    def status(self):
+        """Synchronise and raise if a device-side bounded wait timed out (fused path)."""
+        if self._handle is not None:
+            _native.check(_native.lib().camd_sgbm_status(self._handle, _native.current_stream()),
+                          "StereoSGBM")
 
     # -- cv2-style accessors ---------------------------------------------------------------------
     def _get(self, k):
@@ -97,6 +113,8 @@ class StereoSGBM:
         self._handle, self._key, self._max_batch = hd, key, batch
         if self.profiling:
             _native.check(_native.lib().camd_sgbm_set_profiling(self._handle, 1))
+        for opt, val in self._options.items():
+            _native.check(_native.lib().camd_sgbm_set_option(self._handle, opt, val))
 
     def workspace_bytes(self, w, h, cn=1, batch=1):
         p = self._cparams()
@@ -147,6 +165,8 @@ class StereoSGBM:
                 self._handle, left_t.data_ptr(), right_t.data_ptr(), w * cn, h * w * cn, out.data_ptr(),
                 w * 2, h * w * 2, n, _native.current_stream())
             _native.check(rc, "StereoSGBM.compute")
+            if is_np:
+                self.status()  # host path synchronises anyway: surface device-side timeouts here
         res = out.view(n, h, w) if batched else out.view(h, w)
         return res.cpu().numpy() if is_np else res
 

@@ -75,6 +75,13 @@ int camd_sgbm_query(const camd_sgbm* h, int* width1, int* D, int* Dp, int* minX1
  * int16, to dst (device).  which: 0 = matching cost C (incl. +P2), 1 = aggregated S,
  * 2 = raw disparity before median/speckle as int16 [height][width] */
 int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* stream);
+/* options: CAMD_OPT_PATH 0 = fused band-wavefront passes (default where instantiated), 1 = one line-scan
+ * launch per aggregation direction; CAMD_OPT_KEEP_S 1 = the fused path also stores the final S volume
+ * (needed by camd_sgbm_debug_copy(which = 1)). */
+enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1 };
+int camd_sgbm_set_option(camd_sgbm* h, int option, int value);
+/* synchronises `stream` and reports whether a device-side bounded wait of the last computes timed out */
+int camd_sgbm_status(camd_sgbm* h, void* stream);
 /* per-stage GPU time of the last compute, measured with hipEvents on `stream` (enable first).
  * stage names: camd_sgbm_stage_name(i), i in [0, camd_sgbm_num_stages()) */
 int camd_sgbm_set_profiling(camd_sgbm* h, int enable);

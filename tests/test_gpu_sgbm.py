@@ -20,8 +20,17 @@ def _params(cn, D, bs, minD=0, mode=0, **kw):
     return p
 
 
-def _check_stages(oracle, left, right, p, stages=True):
+def _check_stages(oracle, left, right, p, stages=True, paths=(0, 1)):
+    """paths: 0 = fused band-wavefront passes (default product path), 1 = one line scan per direction"""
+    got = None
+    for path in paths:
+        got = _check_stages_path(oracle, left, right, p, stages, path)
+    return got
+
+
+def _check_stages_path(oracle, left, right, p, stages, path):
     m = StereoSGBM_create(**p)
+    m.set_option("path", path).set_option("keep_S", 1)
     got = m.compute(left, right)
     ref = oracle.sgbm_compute(left, right, **p)
     if stages and m.geometry()["width1"] > 0:
