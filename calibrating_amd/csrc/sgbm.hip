@@ -105,91 +105,116 @@ __global__ __launch_bounds__(256) void k_bt_prepare(const uint8_t* __restrict__ 
 // OpenCV's CostType), pix = sum over channels of min(c0, c1) [gradient] + min(c0, c1) >> 2 [raw].
 // One wave: row y, 64 consecutive d (lane j <-> d = dblk*64 + j), cost columns [xs, xe).
 // ------------------------------------------------------------------------------------------------
-static constexpr int HSUM_SEG = 128;   // cost columns per wave
-static constexpr int HSUM_WAVES = 4;   // waves per workgroup
+static constexpr int HSUM_SEG = 128;   // cost columns per workgroup
 static constexpr int HSUM_RING = 16;   // ring slots (>= 2*SW2+1), per lane, in LDS
 
+// One workgroup = one row y, cost columns [xs, xe), ALL disparities: wave w owns d in [64w, 64w+64).
+// The right-image operands of the row segment are staged once in LDS (entry = one right pixel,
+// CN*3 dwords padded to a multiple of 16 bytes); lane j of wave w reads entry (c - clo) + last - d for
+// cost column c, so every step costs three ds_read_b128 (RGB) instead of VALU shifts.  The left-image
+// operands are wave-uniform scalar loads.
 template <int CN>
-__global__ __launch_bounds__(64 * HSUM_WAVES) void k_hsum(const uint32_t* __restrict__ Lpk,
-                                                          const uint32_t* __restrict__ Rpk,
-                                                          uint16_t* __restrict__ Hs, Geom g, int nseg,
-                                                          int ndblk, size_t vol_stride)
+__global__ __launch_bounds__(512) void k_hsum(const uint32_t* __restrict__ Lpk,
+                                              const uint32_t* __restrict__ Rpk,
+                                              uint16_t* __restrict__ Hs, Geom g, int ndblk, size_t vol_stride)
 {
-    __shared__ uint32_t ring[HSUM_WAVES][HSUM_RING][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // work item = (segment, dblk) of row y
-    int item = blockIdx.x * HSUM_WAVES + wv;
-    if (item >= nseg * ndblk) return;  // whole wave exits
-    const int seg = item / ndblk, dblk = item % ndblk;
+    constexpr int ES = CN == 1 ? 4 : 12;  // dwords per staged right pixel
+    extern __shared__ __attribute__((aligned(16))) uint32_t hs_lds[];
+    const int lane = threadIdx.x & 63, dblk = threadIdx.x >> 6;
     const int y = blockIdx.y, pair = blockIdx.z;
-    const int xs = seg * HSUM_SEG, xe = min(xs + HSUM_SEG, g.W1);
+    const int xs = blockIdx.x * HSUM_SEG, xe = min(xs + HSUM_SEG, g.W1);
     const int d = dblk * 64 + lane;
     const int K = 2 * g.SW2 + 1;
+    const int clo = max(xs - g.SW2, 0), chi = min(xe - 1 + g.SW2, g.W1 - 1);
+    const int last = ndblk * 64 - 1;
+    const int ncols = (chi - clo) + ndblk * 64;
+    const int colbase = clo + g.minX1 - g.minD - last;  // right-image column of entry 0
+    uint32_t* stage = hs_lds;                            // [ncols][ES]
+    uint32_t* ring = hs_lds + (size_t)(HSUM_SEG + 2 * g.SW2 + ndblk * 64) * ES + (size_t)dblk * HSUM_RING * 64;
     const size_t rowbase = ((size_t)pair * g.H + y) * (size_t)g.W;
     const uint32_t* __restrict__ Lrow = Lpk + rowbase * (CN * 3);
     const uint32_t* __restrict__ Rrow = Rpk + rowbase * (CN * 3);
+
+    for (int i = threadIdx.x; i < ncols; i += blockDim.x) {
+        int col = min(max(colbase + i, 0), g.W - 1);  // columns outside the image belong to unused d
+        const uint32_t* p = Rrow + (size_t)col * (CN * 3);
+#pragma unroll
+        for (int k = 0; k < CN * 3; k++) stage[i * ES + k] = p[k];
+    }
+    // left operands of the visited cost columns [clo, chi]: same entry layout, read as LDS broadcasts
+    uint32_t* lstage = hs_lds + (size_t)(HSUM_SEG + 2 * g.SW2 + ndblk * 64) * ES + (size_t)ndblk * HSUM_RING * 64;
+    for (int i = threadIdx.x; i <= chi - clo; i += blockDim.x) {
+        const uint32_t* p = Lrow + (size_t)(clo + i + g.minX1) * (CN * 3);
+#pragma unroll
+        for (int k = 0; k < CN * 3; k++) lstage[i * ES + k] = p[k];
+    }
+    for (int s = 0; s < HSUM_RING; s++) ring[s * 64 + lane] = 0;
+    __syncthreads();
+    const uint4* lent = reinterpret_cast<const uint4*>(lstage);
+
     uint16_t* __restrict__ out = Hs + (size_t)pair * vol_stride + ((size_t)y * g.W1) * g.Dp + d;
     const bool wr_valid = d < g.D, wr_pad = d < g.Dp;
+    const uint4* ent = reinterpret_cast<const uint4*>(stage) + (size_t)(last - d) * (ES / 4);
 
-    // first real cost column visited and its right-image column for this lane
-    int t0 = xs - g.SW2;
-    int c0 = min(max(t0, 0), g.W1 - 1);
-    uint32_t V[CN], V0[CN], V1[CN];
-    {
-        int xr = c0 + g.minX1 - d - g.minD;
-        xr = min(max(xr, 0), g.W - 1);  // lanes with d >= D may point outside; value unused
-        const uint32_t* p = Rrow + (size_t)xr * (CN * 3);
-#pragma unroll
-        for (int c = 0; c < CN; c++) { V[c] = p[c * 3]; V0[c] = p[c * 3 + 1]; V1[c] = p[c * 3 + 2]; }
-    }
-    for (int s = 0; s < HSUM_RING; s++) ring[wv][s][lane] = 0;
-
-    uint32_t run = 0, pix = 0;
-    int cur = c0 - 1;  // forces evaluation at the first step
-    int slot = 0;
-    const int t1 = xe - 1 + g.SW2;
-    for (int t = t0; t <= t1; t++) {
-        int ct = min(max(t, 0), g.W1 - 1);
-        if (ct != cur) {  // wave-uniform
-            if (cur >= c0) {
-                // advance the shift register: lane j takes lane j-1's operands, lane 0 the new column
-                int xr0 = __builtin_amdgcn_readfirstlane(ct + g.minX1 - dblk * 64 - g.minD);
-                xr0 = min(max(xr0, 0), g.W - 1);
-                const uint32_t* p = Rrow + (size_t)xr0 * (CN * 3);
-#pragma unroll
-                for (int c = 0; c < CN; c++) {
-                    V[c] = dpp_mov<DPP_WAVE_SHR1>(p[c * 3], V[c]);
-                    V0[c] = dpp_mov<DPP_WAVE_SHR1>(p[c * 3 + 1], V0[c]);
-                    V1[c] = dpp_mov<DPP_WAVE_SHR1>(p[c * 3 + 2], V1[c]);
-                }
-            }
-            cur = ct;
-            const uint32_t* q = Lrow + (size_t)__builtin_amdgcn_readfirstlane(ct + g.minX1) * (CN * 3);
-            uint32_t acc = 0;
-#pragma unroll
-            for (int c = 0; c < CN; c++) {
-                uint32_t U = q[c * 3], U0 = q[c * 3 + 1], U1 = q[c * 3 + 2];
-                // c0 = max(0, u - v1, v0 - u), c1 = max(0, v - u1, u0 - v): at most one term of each
-                // pair is non-zero, so OR of the saturating differences is their max
-                uint32_t a = pk_subsat_u16(U, V1[c]) | pk_subsat_u16(V0[c], U);
-                uint32_t b = pk_subsat_u16(V[c], U1) | pk_subsat_u16(U0, V[c]);
-                uint32_t m = pk_min_u16(a, b);
-                m = pk_lshr_u16(m, 0x00020000u);  // raw plane: cost >> 2
-                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, m),
-                                             __builtin_bit_cast(u16x2_t, 0x00010001u), acc, false);
-            }
-            pix = acc;
+    // Software pipeline: the operands of step t+1 (three ds_read_b128 + the scalar loads of the left
+    // pixel) are issued before the arithmetic of step t; two operand sets alternate (loop unrolled by 2).
+    struct Ops { uint32_t V[CN], V0[CN], V1[CN], U[CN], U0[CN], U1[CN]; };
+    auto fetch = [&](int t, Ops& o) {
+        const int ct = min(max(t, 0), g.W1 - 1);  // clamped virtual column (box sum replicates the border)
+        const uint4* e = ent + (size_t)(ct - clo) * (ES / 4);
+        if (CN == 1) {
+            uint4 a = e[0];
+            o.V[0] = a.x; o.V0[0] = a.y; o.V1[0] = a.z;
+        } else {
+            uint4 a = e[0], b = e[1], c = e[2];
+            o.V[0] = a.x; o.V0[0] = a.y; o.V1[0] = a.z;
+            o.V[1 % CN] = a.w; o.V0[1 % CN] = b.x; o.V1[1 % CN] = b.y;
+            o.V[2 % CN] = b.z; o.V0[2 % CN] = b.w; o.V1[2 % CN] = c.x;
         }
-        uint32_t old = ring[wv][slot][lane];
-        ring[wv][slot][lane] = pix;
+        const uint4* q = lent + (size_t)(ct - clo) * (ES / 4);
+        if (CN == 1) {
+            uint4 a = q[0];
+            o.U[0] = a.x; o.U0[0] = a.y; o.U1[0] = a.z;
+        } else {
+            uint4 a = q[0], b = q[1], c = q[2];
+            o.U[0] = a.x; o.U0[0] = a.y; o.U1[0] = a.z;
+            o.U[1 % CN] = a.w; o.U0[1 % CN] = b.x; o.U1[1 % CN] = b.y;
+            o.U[2 % CN] = b.z; o.U0[2 % CN] = b.w; o.U1[2 % CN] = c.x;
+        }
+    };
+    uint32_t run = 0;
+    int slot = 0;
+    const int t0 = xs - g.SW2, t1 = xe - 1 + g.SW2;
+    auto step = [&](int t, const Ops& o, Ops& nxt) {
+        fetch(min(t + 1, t1), nxt);
+        uint32_t old = ring[slot * 64 + lane];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int c = 0; c < CN; c++) {
+            // c0 = max(0, u - v1, v0 - u), c1 = max(0, v - u1, u0 - v): at most one term of each pair is
+            // non-zero, so OR of the saturating differences is their max
+            uint32_t a = pk_subsat_u16(o.U[c], o.V1[c]) | pk_subsat_u16(o.V0[c], o.U[c]);
+            uint32_t b = pk_subsat_u16(o.V[c], o.U1[c]) | pk_subsat_u16(o.U0[c], o.V[c]);
+            uint32_t m = pk_min_u16(a, b);
+            m = pk_lshr_u16(m, 0x00020000u);  // raw plane: cost >> 2
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, m),
+                                         __builtin_bit_cast(u16x2_t, 0x00010001u), acc, false);
+        }
+        ring[slot * 64 + lane] = acc;
         slot = slot + 1 == K ? 0 : slot + 1;
-        run += pix - old;
+        run += acc - old;
         int xo = t - g.SW2;
         if (xo >= xs) {
-            uint16_t* o = out + (size_t)xo * g.Dp;
-            if (wr_valid) *o = (uint16_t)run;
-            else if (wr_pad) *o = 0;
+            uint16_t* o16 = out + (size_t)xo * g.Dp;
+            if (wr_valid) *o16 = (uint16_t)run;
+            else if (wr_pad) *o16 = 0;
         }
+    };
+    Ops A, B;
+    fetch(t0, A);
+    for (int t = t0; t <= t1; t += 2) {
+        step(t, A, B);
+        if (t + 1 <= t1) step(t + 1, B, A);
     }
 }
 
@@ -830,13 +855,14 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     MARK(ST_HSUM);
     {
         int nseg = div_up(g.W1, HSUM_SEG), ndblk = div_up(g.Dp, 64);
-        dim3 grid(div_up((long long)nseg * ndblk, HSUM_WAVES), g.H, batch);
+        dim3 grid(nseg, g.H, batch), block(64 * ndblk);
+        const int es = g.cn == 1 ? 4 : 12;
+        size_t lds = ((size_t)(HSUM_SEG + 2 * g.SW2 + ndblk * 64) * es + (size_t)ndblk * HSUM_RING * 64 +
+                      (size_t)(HSUM_SEG + 2 * g.SW2) * es) * 4;
         if (g.cn == 1)
-            hipLaunchKernelGGL((k_hsum<1>), grid, dim3(64 * HSUM_WAVES), 0, st, h->Lpk, h->Rpk, h->S, g, nseg,
-                               ndblk, h->vol_elems);
+            hipLaunchKernelGGL((k_hsum<1>), grid, block, lds, st, h->Lpk, h->Rpk, h->S, g, ndblk, h->vol_elems);
         else
-            hipLaunchKernelGGL((k_hsum<3>), grid, dim3(64 * HSUM_WAVES), 0, st, h->Lpk, h->Rpk, h->S, g, nseg,
-                               ndblk, h->vol_elems);
+            hipLaunchKernelGGL((k_hsum<3>), grid, block, lds, st, h->Lpk, h->Rpk, h->S, g, ndblk, h->vol_elems);
         CAMD_LAUNCH_CHECK();
     }
 

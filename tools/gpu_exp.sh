@@ -8,7 +8,6 @@ for l in sys.stdin:
 "; }
 timeout 900 python -m pytest tests/test_gpu_sgbm.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
 ENVV=(A=1)
-run --mode hh --batch 16
-run --mode hh --batch 64
 run --mode sgbm --batch 64
 run --mode sgbm --batch 64 --channels 1
+run --mode hh --batch 64
