@@ -114,11 +114,12 @@ static constexpr int HSUM_RING = 16;   // ring slots (>= 2*SW2+1), per lane, in 
 // cost column c, so every step costs three ds_read_b128 (RGB) instead of VALU shifts.  The left-image
 // operands are wave-uniform scalar loads.
 template <int CN>
-__global__ __launch_bounds__(512) void k_hsum(const uint32_t* __restrict__ Lpk,
-                                              const uint32_t* __restrict__ Rpk,
-                                              uint16_t* __restrict__ Hs, Geom g, int ndblk, size_t vol_stride)
+__global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
+                                              const uint8_t* __restrict__ right, size_t pitch,
+                                              size_t image_stride, uint16_t* __restrict__ Hs, Geom g,
+                                              int ndblk, size_t vol_stride)
 {
-    constexpr int ES = CN == 1 ? 4 : 12;  // dwords per staged right pixel
+    constexpr int ES = CN == 1 ? 4 : 12;  // dwords per staged pixel
     extern __shared__ __attribute__((aligned(16))) uint32_t hs_lds[];
     const int lane = threadIdx.x & 63, dblk = threadIdx.x >> 6;
     const int y = blockIdx.y, pair = blockIdx.z;
@@ -127,28 +128,53 @@ __global__ __launch_bounds__(512) void k_hsum(const uint32_t* __restrict__ Lpk,
     const int K = 2 * g.SW2 + 1;
     const int clo = max(xs - g.SW2, 0), chi = min(xe - 1 + g.SW2, g.W1 - 1);
     const int last = ndblk * 64 - 1;
-    const int ncols = (chi - clo) + ndblk * 64;
-    const int colbase = clo + g.minX1 - g.minD - last;  // right-image column of entry 0
-    uint32_t* stage = hs_lds;                            // [ncols][ES]
-    uint32_t* ring = hs_lds + (size_t)(HSUM_SEG + 2 * g.SW2 + ndblk * 64) * ES + (size_t)dblk * HSUM_RING * 64;
-    const size_t rowbase = ((size_t)pair * g.H + y) * (size_t)g.W;
-    const uint32_t* __restrict__ Lrow = Lpk + rowbase * (CN * 3);
-    const uint32_t* __restrict__ Rrow = Rpk + rowbase * (CN * 3);
+    const int ncols = (chi - clo) + ndblk * 64;          // right-image entries
+    const int nleft = chi - clo + 1;                      // left-image entries (cost columns clo..chi)
+    const int colbase = clo + g.minX1 - g.minD - last;    // right-image column of entry 0
+    const int maxr = HSUM_SEG + 2 * g.SW2 + ndblk * 64, maxl = HSUM_SEG + 2 * g.SW2;
+    uint32_t* stage = hs_lds;                              // [maxr][ES]   right operands
+    uint32_t* ringb = stage + (size_t)maxr * ES;           // [ndblk][RING][64]
+    uint32_t* ring = ringb + (size_t)dblk * HSUM_RING * 64;
+    uint32_t* lstage = ringb + (size_t)ndblk * HSUM_RING * 64;  // [maxl][ES]  left operands
+    uint32_t* ptmp = lstage + (size_t)maxl * ES;           // [(maxr+2) + (maxl+2)][CN] raw planes
 
-    for (int i = threadIdx.x; i < ncols; i += blockDim.x) {
-        int col = min(max(colbase + i, 0), g.W - 1);  // columns outside the image belong to unused d
-        const uint32_t* p = Rrow + (size_t)col * (CN * 3);
+    // ---- fused calcPixelCostBT preprocessing: planes p = (clipped x-Sobel | raw << 16) of the image
+    // columns this segment touches, then per entry (p, min(p,(p+l)/2,(p+r)/2), max(...)).  Columns 0 and
+    // W-1 of every plane hold ftzero; at the image edge the missing neighbour is p itself.
+    const uint32_t ftz2 = (uint32_t)g.ftzero | ((uint32_t)g.ftzero << 16);
+    auto plane = [&](const uint8_t* img, int col, int c) -> uint32_t {
+        if (col <= 0 || col >= g.W - 1) return ftz2;  // also covers columns outside the image (unused d)
+        const uint8_t* r0 = img + (size_t)y * pitch + (size_t)col * CN + c;
+        const uint8_t* rm = img + (size_t)(y > 0 ? y - 1 : y) * pitch + (size_t)col * CN + c;
+        const uint8_t* rp = img + (size_t)(y < g.H - 1 ? y + 1 : y) * pitch + (size_t)col * CN + c;
+        int gq = ((int)r0[CN] - (int)r0[-CN]) * 2 + ((int)rm[CN] - (int)rm[-CN]) + ((int)rp[CN] - (int)rp[-CN]);
+        gq = min(max(gq, -g.ftzero), g.ftzero) + g.ftzero;
+        return (uint32_t)gq | ((uint32_t)r0[0] << 16);
+    };
+    const uint8_t* imgR = right + (size_t)pair * image_stride;
+    const uint8_t* imgL = left + (size_t)pair * image_stride;
+    uint32_t* ptmpL = ptmp + (size_t)(maxr + 2) * CN;
+    for (int i = threadIdx.x; i < ncols + 2; i += blockDim.x)
 #pragma unroll
-        for (int k = 0; k < CN * 3; k++) stage[i * ES + k] = p[k];
-    }
-    // left operands of the visited cost columns [clo, chi]: same entry layout, read as LDS broadcasts
-    uint32_t* lstage = hs_lds + (size_t)(HSUM_SEG + 2 * g.SW2 + ndblk * 64) * ES + (size_t)ndblk * HSUM_RING * 64;
-    for (int i = threadIdx.x; i <= chi - clo; i += blockDim.x) {
-        const uint32_t* p = Lrow + (size_t)(clo + i + g.minX1) * (CN * 3);
+        for (int c = 0; c < CN; c++) ptmp[i * CN + c] = plane(imgR, colbase - 1 + i, c);
+    for (int i = threadIdx.x; i < nleft + 2; i += blockDim.x)
 #pragma unroll
-        for (int k = 0; k < CN * 3; k++) lstage[i * ES + k] = p[k];
-    }
+        for (int c = 0; c < CN; c++) ptmpL[i * CN + c] = plane(imgL, clo + g.minX1 - 1 + i, c);
     for (int s = 0; s < HSUM_RING; s++) ring[s * 64 + lane] = 0;
+    __syncthreads();
+    auto finish = [&](const uint32_t* pt, uint32_t* dst, int i, int col) {
+#pragma unroll
+        for (int c = 0; c < CN; c++) {
+            uint32_t u = pt[(i + 1) * CN + c], l = pt[i * CN + c], r = pt[(i + 2) * CN + c];
+            uint32_t ul = col > 0 ? pk_lshr_u16(pk_add_u16(u, l), 0x00010001u) : u;
+            uint32_t ur = col < g.W - 1 ? pk_lshr_u16(pk_add_u16(u, r), 0x00010001u) : u;
+            dst[i * ES + c * 3 + 0] = u;
+            dst[i * ES + c * 3 + 1] = pk_min_u16(pk_min_u16(ul, ur), u);
+            dst[i * ES + c * 3 + 2] = pk_max_u16(pk_max_u16(ul, ur), u);
+        }
+    };
+    for (int i = threadIdx.x; i < ncols; i += blockDim.x) finish(ptmp, stage, i, colbase + i);
+    for (int i = threadIdx.x; i < nleft; i += blockDim.x) finish(ptmpL, lstage, i, clo + g.minX1 + i);
     __syncthreads();
     const uint4* lent = reinterpret_cast<const uint4*>(lstage);
 
@@ -715,8 +741,6 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     if (w1 > 0) {
         if (e == hipSuccess) e = hipMalloc((void**)&h->C, (size_t)max_batch * h->vol_elems * 2);
         if (e == hipSuccess) e = hipMalloc((void**)&h->S, (size_t)max_batch * h->vol_elems * 2);
-        if (e == hipSuccess) e = hipMalloc((void**)&h->Lpk, (size_t)max_batch * h->pk_elems * 4);
-        if (e == hipSuccess) e = hipMalloc((void**)&h->Rpk, (size_t)max_batch * h->pk_elems * 4);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->raw, (size_t)max_batch * raw_e * 2);
     size_t sws = speckle_ws_bytes(width, height, max_batch);
@@ -847,22 +871,20 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         return CAMD_OK;
     }
 
-    MARK(ST_PREP);
-    hipLaunchKernelGGL(k_bt_prepare, dim3(div_up(g.W, 256), g.H, batch * 2), dim3(256), 0, st, left, right,
-                       pitch, image_stride, h->Lpk, h->Rpk, g.W, g.H, g.cn, g.ftzero);
-    CAMD_LAUNCH_CHECK();
-
+    MARK(ST_PREP);  // (the BT plane preprocessing is fused into k_hsum's LDS staging)
     MARK(ST_HSUM);
     {
         int nseg = div_up(g.W1, HSUM_SEG), ndblk = div_up(g.Dp, 64);
         dim3 grid(nseg, g.H, batch), block(64 * ndblk);
         const int es = g.cn == 1 ? 4 : 12;
-        size_t lds = ((size_t)(HSUM_SEG + 2 * g.SW2 + ndblk * 64) * es + (size_t)ndblk * HSUM_RING * 64 +
-                      (size_t)(HSUM_SEG + 2 * g.SW2) * es) * 4;
+        const size_t maxr = HSUM_SEG + 2 * g.SW2 + ndblk * 64, maxl = HSUM_SEG + 2 * g.SW2;
+        size_t lds = (maxr * es + (size_t)ndblk * HSUM_RING * 64 + maxl * es + (maxr + maxl + 4) * g.cn) * 4;
         if (g.cn == 1)
-            hipLaunchKernelGGL((k_hsum<1>), grid, block, lds, st, h->Lpk, h->Rpk, h->S, g, ndblk, h->vol_elems);
+            hipLaunchKernelGGL((k_hsum<1>), grid, block, lds, st, left, right, pitch, image_stride, h->S, g, ndblk,
+                               h->vol_elems);
         else
-            hipLaunchKernelGGL((k_hsum<3>), grid, block, lds, st, h->Lpk, h->Rpk, h->S, g, ndblk, h->vol_elems);
+            hipLaunchKernelGGL((k_hsum<3>), grid, block, lds, st, left, right, pitch, image_stride, h->S, g, ndblk,
+                               h->vol_elems);
         CAMD_LAUNCH_CHECK();
     }
 
