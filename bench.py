@@ -4,9 +4,14 @@
 A step = one pass of the SGBM hot path (BT cost volume -> path aggregation -> WTA / uniqueness /
 LR check -> median) over one batch of synthetic rectified pairs that are already resident in HBM.
 Independent pairs shard across ranks with no data-path collective ("scaling": "weak": every rank
-processes its own batch); the only RCCL traffic is the one-time broadcast of the rig's remap tables
-and the end-of-run timing reduction.  Launch: python bench.py [--gpus N --steps K --warmup W]; for
-N > 1 through torch.distributed.run, one rank per GPU.
+processes its own batch of --batch pairs); the only RCCL traffic is the one-time broadcast of the rig's
+remap tables and the end-of-run timing reduction.  Launch: python bench.py [--gpus N --steps K
+--warmup W]; for N > 1 through torch.distributed.run, one rank per GPU.
+
+Default workload = BASELINE.json configs[1]/[2]: 1920x1080 RGB pairs (the reference feeds RGB), D=128,
+blockSize=5, cv2's default MODE_SGBM (5 paths: the mode the reference's cv2.StereoSGBM_create call
+selects), 64 pairs per GPU per step (512 pairs / 8 GPUs).  --mode hh runs the 8-path MODE_HH; its
+throughput is also reported in "also" on every default run.
 """
 import argparse
 import json
@@ -25,26 +30,29 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--disparities", type=int, default=128)
     ap.add_argument("--block", type=int, default=5)
     ap.add_argument("--channels", type=int, default=3, help="3 = RGB as the reference feeds SGBM, 1 = gray")
-    ap.add_argument("--mode", default="hh", choices=["sgbm", "hh"],
-                    help="hh = 8-path MODE_HH (north star), sgbm = 5-path MODE_SGBM (the reference's call)")
+    ap.add_argument("--mode", default="sgbm", choices=["sgbm", "hh"],
+                    help="sgbm = 5-path MODE_SGBM (the reference's call), hh = 8-path MODE_HH")
+    ap.add_argument("--path", type=int, default=0, help="0 = fused band-wavefront passes, 1 = one scan per direction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = one per core)")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary (other mode / gray) measurements")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="strips in the CPU baseline sample (0 = one per thread)")
     return ap.parse_args()
 
 
-def sgbm_params(a):
+def sgbm_params(a, mode=None):
     cn, bs = a.channels, a.block
+    mode = a.mode if mode is None else mode
     return dict(minDisparity=0, numDisparities=a.disparities, blockSize=bs, P1=8 * cn * bs * bs,
                 P2=32 * cn * bs * bs, disp12MaxDiff=1, preFilterCap=0, uniquenessRatio=10,
-                speckleWindowSize=0, speckleRange=0, mode=1 if a.mode == "hh" else 0)
+                speckleWindowSize=0, speckleRange=0, mode=1 if mode == "hh" else 0)
 
 
 def algorithmic_bytes_per_pair(W, H, D, cn, minD=0):
@@ -62,10 +70,11 @@ def cpu_baseline(a, params):
     oracle.build()
     threads = min(os.cpu_count() or 1, 32)
     n = a.cpu_pairs or threads
-    # bounded sample: full-width strips of a quarter of the rows (SGBM cost is linear in rows), one
-    # strip per thread; scaled back to whole pairs below
-    frac = 4
+    # bounded sample (~10-30 s of CPU work): full-width strips of half the rows (SGBM cost is linear in
+    # rows), two strips per thread; scaled back to whole pairs below
+    frac = 2
     hs = max(a.height // frac, 16)
+    n = n * 2 if not a.cpu_pairs else n
     base_l, base_r = synthetic.rectified_pair(seed=1234, H=hs, W=a.width, D=a.disparities, cn=a.channels)
     lefts, rights = [], []
     for i in range(n):  # distinct strips: vertical rolls of one generated strip
@@ -78,9 +87,29 @@ def cpu_baseline(a, params):
     pairs = n * hs / a.height
     return dict(value=pairs / dt, unit="pairs/s", cores=threads, kind="port",
                 sample="%d strips of %dx%d (= %.2f pairs of %dx%d) D=%d cn=%d mode=%s, scalar C port "
-                       "oracle/sgbm_ref.c, %d OpenMP threads (one strip each), %.1f s"
+                       "oracle/sgbm_ref.c, %d OpenMP threads across strips, %.1f s"
                        % (n, a.width, hs, pairs, a.width, a.height, a.disparities, a.channels, a.mode,
                           threads, dt))
+
+
+def timed_steps(matcher, left, right, out, steps, warmup, barrier=None):
+    """K timed steps bracketed by barrier + synchronize; returns (seconds, {stage: ms summed})."""
+    import torch
+    for _ in range(warmup):
+        matcher.compute(left, right, out=out)
+    stage_ms = {}
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        matcher.compute(left, right, out=out)
+        for k, v in matcher.stage_times_ms().items():  # hipEvents on the compute stream
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0, stage_ms
 
 
 def main():
@@ -90,7 +119,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
+    if world > 1:
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     torch.cuda.set_device(local_rank)
@@ -106,11 +135,10 @@ def main():
 
     params = sgbm_params(a)
     # one-time table broadcast (rank 0 owns the rig; every rank needs maps + mask for get_depth)
-    bundle = None
-    if rank == 0:
-        bundle = ca.Stereo.load(synthetic.rig(a.width, a.height)).table_bundle()
-    tables = broadcast_tables(bundle, dev, src=0) if distributed else None
-    del tables
+    if distributed:
+        bundle = ca.Stereo.load(synthetic.rig(a.width, a.height)).table_bundle() if rank == 0 else None
+        tables = broadcast_tables(bundle, dev, src=0)
+        del tables
 
     # this rank's shard of the global pair list: pairs [lo, hi) of world*batch
     lo, hi = shard_range(world * a.batch, world, rank)
@@ -119,26 +147,11 @@ def main():
                                                   a.channels, dev)
     matcher = ca.StereoSGBM_create(**params)
     matcher.set_profiling(True)
+    matcher.set_option("path", a.path)
     out = torch.empty((nb, a.height, a.width), dtype=torch.int16, device=dev)
 
-    def step():
-        matcher.compute(left, right, out=out)
-
-    for _ in range(a.warmup):
-        step()
-    stage_ms = {}
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-        for k, v in matcher.stage_times_ms().items():  # hipEvents on the compute stream
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, stage_ms = timed_steps(matcher, left, right, out, a.steps, a.warmup, dist.barrier if distributed else None)
+    matcher.status()  # raises if a device-side bounded wait timed out
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -148,13 +161,43 @@ def main():
     total_pairs = world * a.batch * a.steps
     value = total_pairs / dt
 
+    also = {}
+    if rank == 0 and world == 1 and not a.no_also:
+        del matcher
+        # the other aggregation mode on the same inputs, and the gray variant of the headline mode
+        other = "hh" if a.mode == "sgbm" else "sgbm"
+        m2 = ca.StereoSGBM_create(**sgbm_params(a, other))
+        m2.set_profiling(True)
+        m2.set_option("path", a.path)
+        d2, _ = timed_steps(m2, left, right, out, a.steps, 1)
+        also["%s_%s_pairs_per_s" % ("rgb" if a.channels == 3 else "gray", other)] = nb * a.steps / d2
+        del m2
+        if a.channels == 3:
+            g = argparse.Namespace(**vars(a))
+            g.channels = 1
+            m3 = ca.StereoSGBM_create(**sgbm_params(g))
+            m3.set_profiling(True)
+            m3.set_option("path", a.path)
+            gl, gr = left[..., 1].contiguous(), right[..., 1].contiguous()
+            d3, _ = timed_steps(m3, gl, gr, out, a.steps, 1)
+            also["gray_%s_pairs_per_s" % a.mode] = nb * a.steps / d3
+            del m3, gl, gr
+
     if rank == 0:
         b_alg, V = algorithmic_bytes_per_pair(a.width, a.height, a.disparities, a.channels)
-        npaths = 8 if a.mode == "hh" else 5
         gpu_ms_step = sum(stage_ms.values()) / a.steps
         achieved = b_alg * nb / (gpu_ms_step * 1e-3) / 1e9
-        scan_ms_launch = stage_ms.get("scan", 0.0) / a.steps / npaths
-        scan_bytes_launch = (3 * npaths - 1) / npaths * V * nb
+        if a.path == 0:
+            # fused band passes: C read once per pass; S written (first), read+written (middle), read (last)
+            npass = 4 if a.mode == "hh" else 2
+            vols = 10 if a.mode == "hh" else 4
+            kname = "k_band (fused aggregation pass: up to 3 directions, last pass + WTA)"
+        else:
+            npass = 8 if a.mode == "hh" else 5
+            vols = 3 * npass - 1
+            kname = "k_scan (one aggregation direction)"
+        k_ms = stage_ms.get("scan", 0.0) / a.steps / npass
+        k_bytes = vols / npass * V * nb
         line = {
             "metric": "stereo pairs/s at 1920x1080 numDisparities=128",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -167,18 +210,20 @@ def main():
                        "pairs_per_gpu_per_step": a.batch, "global_pairs_per_step": world * a.batch,
                        "parallelism": "pairs sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {
-                "bound": "hbm", "kernel": "SGBM pipeline (all launches of one step)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": kname,
+                "achieved": k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else None,
                 "traffic": None,
-                "algorithmic_bytes_per_pair": b_alg, "gpu_ms_per_step": gpu_ms_step,
+                "launches_per_step": npass, "avg_ms_per_launch": k_ms,
+                "algorithmic_bytes_per_launch": k_bytes,
                 "stage_ms_per_step": {k: v / a.steps for k, v in stage_ms.items()},
-                "dominant_kernel": {"name": "k_scan (one aggregation direction)",
-                                    "launches_per_step": npaths, "avg_ms_per_launch": scan_ms_launch,
-                                    "algorithmic_bytes_per_launch": scan_bytes_launch,
-                                    "achieved_GBps": scan_bytes_launch / (scan_ms_launch * 1e-3) / 1e9
-                                    if scan_ms_launch > 0 else None},
+                "pipeline": {"algorithmic_bytes_per_pair": b_alg, "gpu_ms_per_step": gpu_ms_step,
+                             "achieved": achieved, "frac": achieved / HBM_PEAK_GBS},
             },
         }
+        if also:
+            line["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a, params)
         print(json.dumps(line))

@@ -5,12 +5,13 @@
 // (/root/reference/calibrating/stereo_matching.py:48-58,63).  Not a port of OpenCV's row-incremental
 // CPU loop: the algorithm is re-stated in a data-parallel form (SURVEY.md Appendix A / DESIGN.md):
 //
-//   k_bt_prepare   per pixel: clipped x-Sobel + raw planes and their half-pixel min/max, packed as
-//                  (gradient | raw << 16) u16 pairs so the BT cost runs on packed 16-bit VALU ops
-//   k_hsum         Birchfield-Tomasi cost + horizontal box sum.  One wave = 64 consecutive
-//                  disparities of one row; the right-image operands live in a wave-wide shift
-//                  register (DPP wave_shr:1), the left-image operands are wave-uniform scalars
+//   k_hsum         calcPixelCostBT + horizontal box sum.  A workgroup owns (row, 128 cost columns, all d):
+//                  it builds the clipped x-Sobel / raw planes and their half-pixel min/max of the image
+//                  columns it touches in LDS, packed (gradient | raw << 16) so the BT cost runs on packed
+//                  16-bit VALU ops; one wave = 64 consecutive disparities, lane j reads the right-image
+//                  entry of column x - d with ds_read_b128, the left entry is an LDS broadcast
 //   k_vsum         vertical box sum + P2  ->  C[y][x][d]  (int16, d fastest)
+//   k_band         (sgbm_band.hpp) fused aggregation: up to three directions per pass + WTA in the last
 //   k_scan         one aggregation direction as independent line scans from a zero border state;
 //                  a line is owned by a 2..16-lane group (8*NV disparities per lane, packed u16x2),
 //                  neighbours d-1 / d+1 by DPP row shifts, min over d by a DPP butterfly
@@ -43,67 +44,8 @@ struct Geom {
 };
 
 // ------------------------------------------------------------------------------------------------
-// k_bt_prepare: planes of calcPixelCostBT, per pixel and channel: 3 dwords
-//   [0] = p   (gradient | raw<<16),  [1] = min(p, (p+left)/2, (p+right)/2),  [2] = max(...)
-// Columns 0 and W-1 of every plane hold ftzero (= tab[0]).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int plane_grad(const uint8_t* __restrict__ r0, const uint8_t* __restrict__ rm,
-                                          const uint8_t* __restrict__ rp, int x, int W, int cn, int c,
-                                          int ftzero)
-{
-    if (x <= 0 || x >= W - 1) return ftzero;
-    int a = x * cn + c;
-    int g = ((int)r0[a + cn] - (int)r0[a - cn]) * 2 + ((int)rm[a + cn] - (int)rm[a - cn]) +
-            ((int)rp[a + cn] - (int)rp[a - cn]);
-    g = min(max(g, -ftzero), ftzero) + ftzero;
-    return g;
-}
-__device__ __forceinline__ int plane_raw(const uint8_t* __restrict__ r0, int x, int W, int cn, int c,
-                                         int ftzero)
-{
-    if (x <= 0 || x >= W - 1) return ftzero;
-    return r0[x * cn + c];
-}
-
-__global__ __launch_bounds__(256) void k_bt_prepare(const uint8_t* __restrict__ left,
-                                                    const uint8_t* __restrict__ right, size_t pitch,
-                                                    size_t image_stride, uint32_t* __restrict__ Lpk,
-                                                    uint32_t* __restrict__ Rpk, int W, int H, int cn,
-                                                    int ftzero)
-{
-    int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
-    int pair = blockIdx.z >> 1, which = blockIdx.z & 1;
-    if (x >= W) return;
-    const uint8_t* img = (which ? right : left) + (size_t)pair * image_stride;
-    uint32_t* out = (which ? Rpk : Lpk) + ((size_t)pair * H * W + (size_t)y * W + x) * (size_t)(cn * 3);
-    const uint8_t* r0 = img + (size_t)y * pitch;
-    const uint8_t* rm = img + (size_t)(y > 0 ? y - 1 : y) * pitch;
-    const uint8_t* rp = img + (size_t)(y < H - 1 ? y + 1 : y) * pitch;
-    for (int c = 0; c < cn; c++) {
-        int g = plane_grad(r0, rm, rp, x, W, cn, c, ftzero);
-        int r = plane_raw(r0, x, W, cn, c, ftzero);
-        int gl = g, gr = g, rl = r, rr = r;
-        if (x > 0) {
-            gl = (g + plane_grad(r0, rm, rp, x - 1, W, cn, c, ftzero)) / 2;
-            rl = (r + plane_raw(r0, x - 1, W, cn, c, ftzero)) / 2;
-        }
-        if (x < W - 1) {
-            gr = (g + plane_grad(r0, rm, rp, x + 1, W, cn, c, ftzero)) / 2;
-            rr = (r + plane_raw(r0, x + 1, W, cn, c, ftzero)) / 2;
-        }
-        int g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
-        int q0 = min(min(rl, rr), r), q1 = max(max(rl, rr), r);
-        out[c * 3 + 0] = (uint32_t)g | ((uint32_t)r << 16);
-        out[c * 3 + 1] = (uint32_t)g0 | ((uint32_t)q0 << 16);
-        out[c * 3 + 2] = (uint32_t)g1 | ((uint32_t)q1 << 16);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_hsum: Hs[y][x][d] = sum_{dx=-SW2..SW2} pix(y, clamp(x+dx, 0, W1-1), d)   (u16, wraps like
 // OpenCV's CostType), pix = sum over channels of min(c0, c1) [gradient] + min(c0, c1) >> 2 [raw].
-// One wave: row y, 64 consecutive d (lane j <-> d = dblk*64 + j), cost columns [xs, xe).
 // ------------------------------------------------------------------------------------------------
 static constexpr int HSUM_SEG = 128;   // cost columns per workgroup
 static constexpr int HSUM_RING = 16;   // ring slots (>= 2*SW2+1), per lane, in LDS
@@ -543,8 +485,6 @@ struct camd_sgbm {
     camd_sgbm_params params;
     int max_batch;
     size_t vol_elems;     // per pair, int16 elements of one volume
-    size_t pk_elems;      // per pair, dwords of one packed-plane array
-    uint32_t *Lpk, *Rpk;
     uint16_t *C, *S;      // S doubles as the hsum buffer before aggregation
     int16_t* raw;         // [max_batch][H][W] disparity before median
     void* speckle_ws;
@@ -711,9 +651,17 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     if (normalise(p, width, height, channels, &g) != CAMD_OK || max_batch <= 0) return 0;
     size_t w1 = g.W1 > 0 ? (size_t)g.W1 : 0;
     size_t vol = align_up((size_t)height * w1 * g.Dp * 2, 256);
-    size_t pk = align_up((size_t)height * width * channels * 3 * 4, 256);
     size_t raw = align_up((size_t)height * width * 2, 256);
-    return (size_t)max_batch * (2 * vol + 2 * pk + raw) + speckle_ws_bytes(width, height, max_batch);
+    size_t total = (size_t)max_batch * (2 * vol + raw);
+    if (g.speckleWindowSize > 0) total += speckle_ws_bytes(width, height, max_batch);
+    const bool band_ok = w1 > 0 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    if (band_ok) {
+        const int R = BAND_THREADS / g.lanes;
+        size_t nb = (size_t)div_up(height, R);
+        total += (size_t)max_batch * nb * ((size_t)g.W1 * g.lanes * (4 * g.nv + 1) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
+        total += (size_t)max_batch * height * width * 6 + 8;
+    }
+    return total;
 }
 
 int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int channels, int max_batch,
@@ -735,7 +683,6 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     h->max_batch = max_batch;
     size_t w1 = g.W1 > 0 ? (size_t)g.W1 : 0;
     h->vol_elems = align_up((size_t)height * w1 * g.Dp * 2, 256) / 2;
-    h->pk_elems = align_up((size_t)height * width * channels * 3 * 4, 256) / 4;
     size_t raw_e = align_up((size_t)height * width * 2, 256) / 2;
     hipError_t e = hipSuccess;
     if (w1 > 0) {
@@ -779,7 +726,7 @@ int camd_sgbm_destroy(camd_sgbm* h)
     if (!h) return CAMD_OK;
     if (h->ev_ok)
         for (int i = 0; i <= ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
-    (void)hipFree(h->C); (void)hipFree(h->S); (void)hipFree(h->Lpk); (void)hipFree(h->Rpk);
+    (void)hipFree(h->C); (void)hipFree(h->S);
     (void)hipFree(h->raw); (void)hipFree(h->speckle_ws);
     (void)hipFree(h->E); (void)hipFree(h->flags); (void)hipFree(h->ticket); (void)hipFree(h->keys);
     (void)hipFree(h->d1);
