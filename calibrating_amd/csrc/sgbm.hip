@@ -654,7 +654,7 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     size_t raw = align_up((size_t)height * width * 2, 256);
     size_t total = (size_t)max_batch * (2 * vol + raw);
     if (g.speckleWindowSize > 0) total += speckle_ws_bytes(width, height, max_batch);
-    const bool band_ok = w1 > 0 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    const bool band_ok = w1 > 0 && g.uniq <= 99 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
     if (band_ok) {
         const int R = BAND_THREADS / g.lanes;
         size_t nb = (size_t)div_up(height, R);
@@ -693,7 +693,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     size_t sws = speckle_ws_bytes(width, height, max_batch);
     if (e == hipSuccess && g.speckleWindowSize > 0) e = hipMalloc(&h->speckle_ws, sws);
     // band-wavefront path: instantiated for 16 lanes x {1,2} vectors and 8 lanes x 1 vector
-    h->band_ok = w1 > 0 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    h->band_ok = w1 > 0 && g.uniq <= 99 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
     h->path = 0;
     h->epoch = 0;
     if (h->band_ok) {

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(BAND_BLOCK) void k_band(BandArgs a, Geom g)
     __shared__ uint4 eDl[3][64 * NV];
     __shared__ uint32_t edVl[3][CPB];
     __shared__ uint32_t edDl[3][CPB];
+    __shared__ uint4 wS[MODE == 2 ? BAND_THREADS * NV : 1];  // FINAL: S of the current pixel, per group
     __shared__ uint32_t s_ticket;
 
     if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1u);
@@ -125,10 +126,11 @@ __global__ __launch_bounds__(BAND_BLOCK) void k_band(BandArgs a, Geom g)
     const bool producer = !helper && has_next && grp == glast;
 
     const uint32_t P1pk = dup16((uint32_t)g.P1), P2pk = dup16((uint32_t)g.P2);
-    uint32_t keep[NR], sent[NR];
+    uint32_t keep[NR], sent[NR], dlo[NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         int d0 = li * 8 * NV + 2 * k;
+        dlo[k] = (uint32_t)d0;
         uint32_t kp = (d0 < g.D ? 0xffffu : 0u) | (d0 + 1 < g.D ? 0xffff0000u : 0u);
         keep[k] = kp;
         sent[k] = ~kp & SENT_PK;
@@ -360,46 +362,57 @@ __global__ __launch_bounds__(BAND_BLOCK) void k_band(BandArgs a, Geom g)
                                 sp[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
                         }
                         if (MODE == 2) {
-                            // winner-take-all on the final S of this pixel (same arithmetic as k_wta)
-                            const int dbase = li * 8 * NV;
+                            // ---- winner-take-all on the final S of this pixel (bit-exact with k_wta) ----
+                            // (1) minS and the smallest d attaining it: min over keys (S << 16 | d); padded
+                            //     d >= D hold S = 0x7FFF and never win while a real candidate exists
                             uint32_t key = 0xffffffffu;
 #pragma unroll
                             for (int k = 0; k < NR; k++) {
-                                int d0 = dbase + 2 * k;
-                                uint32_t lo = s[k] & 0xffffu, hi = s[k] >> 16;
-                                if (d0 < g.D) key = min(key, (lo << 16) | (uint32_t)d0);
-                                if (d0 + 1 < g.D) key = min(key, (hi << 16) | (uint32_t)(d0 + 1));
+                                key = min(key, (s[k] << 16) | dlo[k]);
+                                key = min(key, (s[k] & 0xffff0000u) | (dlo[k] + 1u));
                             }
                             key = group_min_u32<LANES>(key);
                             const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
-                            uint32_t fl = 0, sm = 0, spv = 0;
-                            const int thr = minS * 100, mul = 100 - g.uniq;
+                            // park S so that lane 0 can pick S[best-1], S[best+1] without a select tree
+#pragma unroll
+                            for (int v = 0; v < NV; v++)
+                                wS[threadIdx.x * NV + v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
+                            // (2) uniqueness: S[d]*(100-u) < minS*100 for some |d-best| > 1
+                            //     <=>  min over those d of S[d]  <=  T = floor((minS*100 - 1) / (100-u))
+                            int T = -1;
+                            if (minS > 0) T = (int)__fdiv_rn((float)(minS * 100 - 1), (float)(100 - g.uniq));
+                            const int t0 = (int)dlo[0] - (best - 1);  // element offset of this lane from best-1
+                            uint32_t far = SENT_PK | 0x80008000u;      // 0xFFFF in both halves
 #pragma unroll
                             for (int k = 0; k < NR; k++) {
-                                int d0 = dbase + 2 * k;
-                                int lo = (int)(s[k] & 0xffffu), hi = (int)(s[k] >> 16);
-                                if (d0 < g.D) {
-                                    if (lo * mul < thr && abs(best - d0) > 1) fl = 1;
-                                    if (d0 == best - 1) sm = (uint32_t)lo;
-                                    if (d0 == best + 1) spv = (uint32_t)lo;
-                                }
-                                if (d0 + 1 < g.D) {
-                                    if (hi * mul < thr && abs(best - d0 - 1) > 1) fl = 1;
-                                    if (d0 + 1 == best - 1) sm = (uint32_t)hi;
-                                    if (d0 + 1 == best + 1) spv = (uint32_t)hi;
-                                }
+                                const int tk = t0 + 2 * k;
+                                uint32_t ex = ((unsigned)tk < 3u ? 0xffffu : 0u) | ((unsigned)(tk + 1) < 3u ? 0xffff0000u : 0u);
+                                far = pk_min_u16(far, s[k] | ex);
                             }
-                            uint32_t packed = group_or_u32<LANES>((fl << 31) | (sm << 15) | spv);
-                            if (li == 0 && minS < MAX_COST && !(packed >> 31)) {
+                            far = group_min_pk_u16<LANES>(far);
+                            const int minfar = (int)min(far & 0xffffu, far >> 16);
+                            if (li == 0 && minS < MAX_COST && minfar > T) {
                                 const int x = a.sx > 0 ? xi : W1 - 1 - xi;
-                                int Sm = (int)((packed >> 15) & 0x7fffu), Sp = (int)(packed & 0x7fffu);
                                 int d = best;
                                 int x2 = x + g.minX1 - d - g.minD;
                                 const size_t ro = ((size_t)pair * H + y) * (size_t)g.W;
                                 atomicMin(a.keys + ro + x2, ((uint32_t)minS << 16) | (uint32_t)(0xffff - d));
                                 if (0 < d && d < g.D - 1) {
-                                    int denom2 = max(Sm + Sp - 2 * minS, 1);
-                                    d = d * 16 + ((Sm - Sp) * 16 + denom2) / (denom2 * 2);
+                                    const uint16_t* gs = reinterpret_cast<const uint16_t*>(wS) + (size_t)grp * (LANES * 8 * NV);
+                                    const int Sm = gs[d - 1], Sp = gs[d + 1];
+                                    const int denom2 = max(Sm + Sp - 2 * minS, 1);
+                                    const int num = (Sm - Sp) * 16 + denom2, den = denom2 * 2;
+                                    // num / den truncated toward zero; |quotient| <= 8: reciprocal estimate + fix-up
+                                    int q = (int)((float)num * __frcp_rn((float)den));
+                                    int r = num - q * den;
+                                    if (num >= 0) {
+                                        if (r < 0) q--;
+                                        else if (r >= den) q++;
+                                    } else {
+                                        if (r > 0) q++;
+                                        else if (r <= -den) q--;
+                                    }
+                                    d = d * 16 + q;
                                 } else
                                     d *= 16;
                                 a.d1[ro + x + g.minX1] = (int16_t)(d + g.minD * 16);
