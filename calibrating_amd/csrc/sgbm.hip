@@ -73,16 +73,15 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
     const int ncols = (chi - clo) + ndblk * 64;          // right-image entries
     const int nleft = chi - clo + 1;                      // left-image entries (cost columns clo..chi)
     const int colbase = clo + g.minX1 - g.minD - last;    // right-image column of entry 0
-    const int maxr = HSUM_SEG + 2 * g.SW2 + ndblk * 64, maxl = HSUM_SEG + 2 * g.SW2;
-    uint32_t* stage = hs_lds;                              // [maxr][ES]   right operands
-    uint32_t* ringb = stage + (size_t)maxr * ES;           // [ndblk][RING][64]
-    uint32_t* ring = ringb + (size_t)dblk * HSUM_RING * 64;
-    uint32_t* lstage = ringb + (size_t)ndblk * HSUM_RING * 64;  // [maxl][ES]  left operands
-    uint32_t* ptmp = lstage + (size_t)maxl * ES;           // [(maxr+2) + (maxl+2)][CN] raw planes
+    const int maxr = HSUM_SEG + 2 * g.SW2 + ndblk * 64 + 2, maxl = HSUM_SEG + 2 * g.SW2 + 2;
+    uint32_t* stage = hs_lds;                              // [maxr][ES]  right operands (+1 halo entry each side)
+    uint32_t* lstage = stage + (size_t)maxr * ES;          // [maxl][ES]  left operands  (+1 halo entry each side)
+    uint32_t* ring = lstage + (size_t)maxl * ES + (size_t)dblk * K * 64;  // [ndblk][K][64]
 
     // ---- fused calcPixelCostBT preprocessing: planes p = (clipped x-Sobel | raw << 16) of the image
     // columns this segment touches, then per entry (p, min(p,(p+l)/2,(p+r)/2), max(...)).  Columns 0 and
     // W-1 of every plane hold ftzero; at the image edge the missing neighbour is p itself.
+    // Phase 1 writes p into slot 0 of every entry (halo included), phase 2 reads the neighbours' slot 0.
     const uint32_t ftz2 = (uint32_t)g.ftzero | ((uint32_t)g.ftzero << 16);
     auto plane = [&](const uint8_t* img, int col, int c) -> uint32_t {
         if (col <= 0 || col >= g.W - 1) return ftz2;  // also covers columns outside the image (unused d)
@@ -95,34 +94,32 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
     };
     const uint8_t* imgR = right + (size_t)pair * image_stride;
     const uint8_t* imgL = left + (size_t)pair * image_stride;
-    uint32_t* ptmpL = ptmp + (size_t)(maxr + 2) * CN;
-    for (int i = threadIdx.x; i < ncols + 2; i += blockDim.x)
+    for (int e = threadIdx.x; e < ncols + 2; e += blockDim.x)
 #pragma unroll
-        for (int c = 0; c < CN; c++) ptmp[i * CN + c] = plane(imgR, colbase - 1 + i, c);
-    for (int i = threadIdx.x; i < nleft + 2; i += blockDim.x)
+        for (int c = 0; c < CN; c++) stage[e * ES + c * 3] = plane(imgR, colbase - 1 + e, c);
+    for (int e = threadIdx.x; e < nleft + 2; e += blockDim.x)
 #pragma unroll
-        for (int c = 0; c < CN; c++) ptmpL[i * CN + c] = plane(imgL, clo + g.minX1 - 1 + i, c);
-    for (int s = 0; s < HSUM_RING; s++) ring[s * 64 + lane] = 0;
+        for (int c = 0; c < CN; c++) lstage[e * ES + c * 3] = plane(imgL, clo + g.minX1 - 1 + e, c);
+    for (int s = 0; s < K; s++) ring[s * 64 + lane] = 0;
     __syncthreads();
-    auto finish = [&](const uint32_t* pt, uint32_t* dst, int i, int col) {
+    auto finish = [&](uint32_t* dst, int e, int col) {  // entry e >= 1 holds image column col
 #pragma unroll
         for (int c = 0; c < CN; c++) {
-            uint32_t u = pt[(i + 1) * CN + c], l = pt[i * CN + c], r = pt[(i + 2) * CN + c];
+            uint32_t u = dst[e * ES + c * 3], l = dst[(e - 1) * ES + c * 3], r = dst[(e + 1) * ES + c * 3];
             uint32_t ul = col > 0 ? pk_lshr_u16(pk_add_u16(u, l), 0x00010001u) : u;
             uint32_t ur = col < g.W - 1 ? pk_lshr_u16(pk_add_u16(u, r), 0x00010001u) : u;
-            dst[i * ES + c * 3 + 0] = u;
-            dst[i * ES + c * 3 + 1] = pk_min_u16(pk_min_u16(ul, ur), u);
-            dst[i * ES + c * 3 + 2] = pk_max_u16(pk_max_u16(ul, ur), u);
+            dst[e * ES + c * 3 + 1] = pk_min_u16(pk_min_u16(ul, ur), u);
+            dst[e * ES + c * 3 + 2] = pk_max_u16(pk_max_u16(ul, ur), u);
         }
     };
-    for (int i = threadIdx.x; i < ncols; i += blockDim.x) finish(ptmp, stage, i, colbase + i);
-    for (int i = threadIdx.x; i < nleft; i += blockDim.x) finish(ptmpL, lstage, i, clo + g.minX1 + i);
+    for (int i = threadIdx.x; i < ncols; i += blockDim.x) finish(stage, i + 1, colbase + i);
+    for (int i = threadIdx.x; i < nleft; i += blockDim.x) finish(lstage, i + 1, clo + g.minX1 + i);
     __syncthreads();
-    const uint4* lent = reinterpret_cast<const uint4*>(lstage);
+    const uint4* lent = reinterpret_cast<const uint4*>(lstage) + (ES / 4);  // skip the halo entry
 
     uint16_t* __restrict__ out = Hs + (size_t)pair * vol_stride + ((size_t)y * g.W1) * g.Dp + d;
     const bool wr_valid = d < g.D, wr_pad = d < g.Dp;
-    const uint4* ent = reinterpret_cast<const uint4*>(stage) + (size_t)(last - d) * (ES / 4);
+    const uint4* ent = reinterpret_cast<const uint4*>(stage) + (size_t)(last - d + 1) * (ES / 4);
 
     // Software pipeline: the operands of step t+1 (three ds_read_b128 + the scalar loads of the left
     // pixel) are issued before the arithmetic of step t; two operand sets alternate (loop unrolled by 2).
@@ -824,8 +821,8 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         int nseg = div_up(g.W1, HSUM_SEG), ndblk = div_up(g.Dp, 64);
         dim3 grid(nseg, g.H, batch), block(64 * ndblk);
         const int es = g.cn == 1 ? 4 : 12;
-        const size_t maxr = HSUM_SEG + 2 * g.SW2 + ndblk * 64, maxl = HSUM_SEG + 2 * g.SW2;
-        size_t lds = (maxr * es + (size_t)ndblk * HSUM_RING * 64 + maxl * es + (maxr + maxl + 4) * g.cn) * 4;
+        const size_t maxr = HSUM_SEG + 2 * g.SW2 + ndblk * 64 + 2, maxl = HSUM_SEG + 2 * g.SW2 + 2;
+        size_t lds = ((maxr + maxl) * es + (size_t)ndblk * (2 * g.SW2 + 1) * 64) * 4;
         if (g.cn == 1)
             hipLaunchKernelGGL((k_hsum<1>), grid, block, lds, st, left, right, pitch, image_stride, h->S, g, ndblk,
                                h->vol_elems);
