@@ -126,6 +126,30 @@ __device__ __forceinline__ uint32_t group_or_u32(uint32_t v)
     return v;
 }
 
+// Butterflies for groups whose lanes are all active: the DPP source lane is always valid, so no `old`
+// value has to be preserved and the move folds into the VALU op (v_min_u32_dpp: one instruction per step).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_perm(uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, 0xf, 0xf, true);
+}
+template <int LANES>
+__device__ __forceinline__ uint32_t group_min_u32_full(uint32_t v)
+{
+    if (LANES >= 2) v = min(v, dpp_perm<DPP_QUAD_XOR1>(v));
+    if (LANES >= 4) v = min(v, dpp_perm<DPP_QUAD_XOR2>(v));
+    if (LANES >= 8) v = min(v, dpp_perm<DPP_ROW_HALF_MIRROR>(v));
+    if (LANES >= 16) v = min(v, dpp_perm<DPP_ROW_MIRROR>(v));
+    return v;
+}
+// minimum over all u16 of the group's packed values, returned in BOTH halves (ready for packed use)
+template <int LANES>
+__device__ __forceinline__ uint32_t group_min_dup16(uint32_t pk)
+{
+    uint32_t v = pk_min_u16(pk, alignbit16(pk, pk));  // both halves = min(lo, hi)
+    return group_min_u32_full<LANES>(v);              // x * 0x10001 is monotonic in x
+}
+
 static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace camd

@@ -616,7 +616,12 @@ static int launch_band(camd_sgbm* h, int sx, int sy, int dirs, int mode, int bat
     a.nodep = nodep;
     CAMD_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
     dim3 grid(h->nbands * batch), block(BAND_BLOCK);
-#define CAMD_BAND(LN, NVV, DD, MM) hipLaunchKernelGGL((k_band<LN, NVV, DD, MM>), grid, block, 0, st, a, g)
+    const bool pad = g.Dp != g.D;
+#define CAMD_BAND(LN, NVV, DD, MM)                                                                \
+    do {                                                                                          \
+        if (pad) hipLaunchKernelGGL((k_band<LN, NVV, DD, MM, true>), grid, block, 0, st, a, g);   \
+        else hipLaunchKernelGGL((k_band<LN, NVV, DD, MM, false>), grid, block, 0, st, a, g);      \
+    } while (0)
 #define CAMD_BAND_SHAPE(DD, MM)                                   \
     do {                                                          \
         if (g.lanes == 16 && g.nv == 1) CAMD_BAND(16, 1, DD, MM); \

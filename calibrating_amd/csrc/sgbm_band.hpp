@@ -55,7 +55,7 @@ struct BandArgs {
 };
 
 // one SGM update: L = C + min(Lp, Lp[d-1]+P1, Lp[d+1]+P1, delta) - delta, packed u16, returns new delta
-template <int LANES, int NR>
+template <int LANES, int NR, bool PAD>
 __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&Lp)[NR], uint32_t delta, const uint32_t (&c)[NR],
                                              uint32_t (&L)[NR], const uint32_t (&keep)[NR],
                                              const uint32_t (&sent)[NR], uint32_t P1pk, uint32_t P2pk, int li)
@@ -77,17 +77,16 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&Lp)[NR], uint32_t 
         uint32_t t = pk_add_u16(pk_min_u16(m[k], m[k + 1]), P1pk);
         uint32_t a = pk_min_u16(pk_min_u16(Lp[k], t), delta);
         uint32_t l = pk_sub_u16(pk_add_u16(c[k], a), delta);
-        l = (l & keep[k]) | sent[k];
+        if (PAD) l = (l & keep[k]) | sent[k];  // d >= D carries MAX_COST
         L[k] = l;
         mn = pk_min_u16(mn, l);
     }
-    mn = group_min_pk_u16<LANES>(mn);
-    mn = pk_min_u16(mn, alignbit16(mn, mn));
-    return pk_add_u16(mn, P2pk);
+    return pk_add_u16(group_min_dup16<LANES>(mn), P2pk);
 }
 
 // DIRS: bit0 H, bit1 V, bit2 Dg.  MODE: 0 = first pass (S written), 1 = middle (S += ...), 2 = final (WTA)
-template <int LANES, int NV, int DIRS, int MODE>
+// PAD: Dp > D (padded disparities are forced to MAX_COST after every update)
+template <int LANES, int NV, int DIRS, int MODE, bool PAD>
 __global__ __launch_bounds__(BAND_BLOCK) void k_band(BandArgs a, Geom g)
 {
     constexpr int NR = 4 * NV;
@@ -331,12 +330,12 @@ __global__ __launch_bounds__(BAND_BLOCK) void k_band(BandArgs a, Geom g)
                         for (int k = 0; k < NR; k++) s[k] = MODE != 0 ? sr[u][k] : 0u;
                         if (HAS_H) {
                             uint32_t L[NR];
-                            dH = sgm_step<LANES, NR>(LH, dH, cc, L, keep, sent, P1pk, P2pk, li);
+                            dH = sgm_step<LANES, NR, PAD>(LH, dH, cc, L, keep, sent, P1pk, P2pk, li);
 #pragma unroll
                             for (int k = 0; k < NR; k++) { LH[k] = L[k]; s[k] = pk_addsat_i16(s[k], L[k]); }
                         }
                         if (HAS_V) {
-                            dVo = sgm_step<LANES, NR>(Vin, dV, cc, LVo, keep, sent, P1pk, P2pk, li);
+                            dVo = sgm_step<LANES, NR, PAD>(Vin, dV, cc, LVo, keep, sent, P1pk, P2pk, li);
 #pragma unroll
                             for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LVo[k]);
                         }
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(BAND_BLOCK) void k_band(BandArgs a, Geom g)
                             const bool z = xi == 0;  // previous column is outside the array: zero border state
 #pragma unroll
                             for (int k = 0; k < NR; k++) Din[k] = z ? 0u : Dh[k];
-                            dDo = sgm_step<LANES, NR>(Din, z ? P2pk : dDh, cc, LDo, keep, sent, P1pk, P2pk, li);
+                            dDo = sgm_step<LANES, NR, PAD>(Din, z ? P2pk : dDh, cc, LDo, keep, sent, P1pk, P2pk, li);
 #pragma unroll
                             for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LDo[k]);
                         }
@@ -371,7 +370,7 @@ __global__ __launch_bounds__(BAND_BLOCK) void k_band(BandArgs a, Geom g)
                                 key = min(key, (s[k] << 16) | dlo[k]);
                                 key = min(key, (s[k] & 0xffff0000u) | (dlo[k] + 1u));
                             }
-                            key = group_min_u32<LANES>(key);
+                            key = group_min_u32_full<LANES>(key);
                             const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
                             // park S so that lane 0 can pick S[best-1], S[best+1] without a select tree
 #pragma unroll
@@ -389,8 +388,7 @@ __global__ __launch_bounds__(BAND_BLOCK) void k_band(BandArgs a, Geom g)
                                 uint32_t ex = ((unsigned)tk < 3u ? 0xffffu : 0u) | ((unsigned)(tk + 1) < 3u ? 0xffff0000u : 0u);
                                 far = pk_min_u16(far, s[k] | ex);
                             }
-                            far = group_min_pk_u16<LANES>(far);
-                            const int minfar = (int)min(far & 0xffffu, far >> 16);
+                            const int minfar = (int)(group_min_dup16<LANES>(far) & 0xffffu);
                             if (li == 0 && minS < MAX_COST && minfar > T) {
                                 const int x = a.sx > 0 ? xi : W1 - 1 - xi;
                                 int d = best;
