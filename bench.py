@@ -124,7 +124,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # CAMD_BENCH_FORCE_DIST=1 exercises the RCCL path (init, table broadcast, barrier, all-reduce) with a
+    # single rank, e.g. under `python -m torch.distributed.run --nproc-per-node 1`
+    distributed = world > 1 or (os.environ.get("CAMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -198,6 +200,17 @@ def main():
             kname = "k_scan (one aggregation direction)"
         k_ms = stage_ms.get("scan", 0.0) / a.steps / npass
         k_bytes = vols / npass * V * nb
+        # HBM traffic per launch from the committed PMC profile of the same kernels (separate rocprofv3
+        # --pmc passes, 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction); null when no profile matches
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if (a.path == 0 and a.mode == "sgbm" and (a.width, a.height, a.disparities) == (1920, 1080, 128)
+                and os.path.exists(pmc_path)):
+            pmc = json.load(open(pmc_path))
+            per_pair = [v["hbm_bytes_per_pair"] for k, v in pmc["kernels"].items() if "k_band" in k]
+            if per_pair:
+                traffic = sum(per_pair) / len(per_pair) * nb
+                traffic_src = "profiles/r01_pmc_traffic.json (bytes per pair per launch x pairs per launch)"
         line = {
             "metric": "stereo pairs/s at 1920x1080 numDisparities=128",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -214,7 +227,7 @@ def main():
                 "achieved": k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else None,
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": npass, "avg_ms_per_launch": k_ms,
                 "algorithmic_bytes_per_launch": k_bytes,
                 "stage_ms_per_step": {k: v / a.steps for k, v in stage_ms.items()},
