@@ -129,6 +129,7 @@ def main():
     distributed = world > 1 or (os.environ.get("CAMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["NCCL_DEBUG"] = os.environ.get("CAMD_NCCL_DEBUG", "WARN")  # keep RCCL's banner off stdout
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import calibrating_amd as ca

@@ -66,6 +66,8 @@ SIGNATURES = {
     "camd_undistort_maps_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "camd_lanczos4_table_host": (c_int, [c_void_p]),
     "camd_bilinear_table_host": (c_int, [c_void_p]),
+    "camd_resize_linear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "camd_resize_linear_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "camd_disp_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double,
                                    c_double, c_void_p, c_void_p, c_int, c_void_p]),
     "camd_unrectify_depth": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

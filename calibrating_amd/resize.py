@@ -1,11 +1,13 @@
-"""``boxx.resize`` as the reference's matcher uses it (stereo_matching.py:62,66).
+"""``boxx.resize`` as the reference's matcher uses it (stereo_matching.py:62,66), on the GPU.
 
-``resize(img, ratio)`` with ``ratio == 1`` and ``resize(img, (h, w))`` to the current size return
-the input unchanged -- the only cases reached when ``cfg["max_size"] >= max(h, w)``.  A real
-down-/up-scale (cv2.resize INTER_LINEAR) is the "next" row n1 of SURVEY.md section 8f and is not
-built yet: it raises instead of silently substituting another interpolation.
+``resize(img, ratio)`` with ``ratio == 1`` and ``resize(img, (h, w))`` to the current size return the
+input unchanged (the cases reached when ``cfg["max_size"] >= max(h, w)``); anything else runs the
+cv2.resize(..., INTER_LINEAR) kernels of csrc/resize.hip (uint8 HWC images, float32 HW maps).
+torch CUDA tensors in, tensors out.
 """
 import numbers
+
+from . import _native
 
 
 def target_hw(shape_hw, arg):
@@ -17,11 +19,28 @@ def target_hw(shape_hw, arg):
 
 
 def resize(img, arg):
+    import torch
     if isinstance(arg, numbers.Number) and arg == 1:
         return img
     hw = target_hw(tuple(img.shape[:2]), arg)
     if hw == tuple(img.shape[:2]):
         return img
-    raise NotImplementedError(
-        "calibrating_amd: resizing %s -> %s is not implemented on the GPU path yet; construct the matcher "
-        "with cfg['max_size'] >= max(h, w) (SURVEY.md F8)" % (tuple(img.shape[:2]), hw))
+    if not isinstance(img, torch.Tensor) or not img.is_cuda:
+        raise ValueError("resize expects a torch CUDA tensor")
+    img = img.contiguous()
+    sh, sw = img.shape[:2]
+    dh, dw = hw
+    with torch.cuda.device(img.device):
+        if img.dtype == torch.uint8:
+            cn = 1 if img.dim() == 2 else img.shape[2]
+            out = torch.empty((dh, dw) + tuple(img.shape[2:]), dtype=torch.uint8, device=img.device)
+            rc = _native.lib().camd_resize_linear_u8(img.data_ptr(), sw, sh, cn, out.data_ptr(), dw, dh, 1,
+                                                     _native.current_stream())
+        elif img.dtype == torch.float32 and img.dim() == 2:
+            out = torch.empty((dh, dw), dtype=torch.float32, device=img.device)
+            rc = _native.lib().camd_resize_linear_f32(img.data_ptr(), sw, sh, out.data_ptr(), dw, dh, 1,
+                                                      _native.current_stream())
+        else:
+            raise ValueError("resize: unsupported dtype/shape %s %s" % (img.dtype, tuple(img.shape)))
+    _native.check(rc, "resize")
+    return out

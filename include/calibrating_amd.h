@@ -120,6 +120,14 @@ int camd_undistort_maps_host(const double K[9], const double* dist, int ndist, i
 int camd_lanczos4_table_host(int16_t* tab_host);
 int camd_bilinear_table_host(int16_t* tab_host);
 
+/* replaces boxx.resize -> cv2.resize(..., INTER_LINEAR) around the matcher when max(h, w) > cfg["max_size"]:
+ *   stereo_matching.py:62 (u8 RGB pair, downsize)   stereo_matching.py:66 (float32 disparity, upsize)
+ * src [batch][sh][sw][cn], dst [batch][dh][dw][cn], contiguous. */
+int camd_resize_linear_u8(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh, int batch,
+                          void* stream);
+int camd_resize_linear_f32(const float* src, int sw, int sh, float* dst, int dw, int dh, int batch,
+                           void* stream);
+
 /* ---- depth -----------------------------------------------------------------------------------
  * replaces stereo_matching.py:63-69 (int16 -> f32, clip, < minD*16 -> 0, /16, identity resize),
  * stereo_camera.py:510-512 (+= min_disparity, * rectify_valid_mask1) and

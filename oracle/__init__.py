@@ -33,7 +33,7 @@ class Switches(ctypes.Structure):
 
 def build(force=False):
     """Compile oracle/*.c with gcc (Makefile in this directory)."""
-    srcs = [os.path.join(_HERE, f) for f in ("sgbm_ref.c", "remap_ref.c", "depth_ref.c", "oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("sgbm_ref.c", "remap_ref.c", "depth_ref.c", "resize_ref.c", "oracle.h")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
@@ -196,6 +196,25 @@ def undistort_u8(src, K, dist):
     lib().oracle_undistort_u8(_p(src, ctypes.c_uint8), w, h, cn, _p(K, ctypes.c_double),
                               None if dist is None else _p(dist, ctypes.c_double),
                               0 if dist is None else dist.size, _p(dst, ctypes.c_uint8))
+    return dst
+
+
+def resize_linear(src, dsize_hw):
+    """cv2.resize(src, (w, h), interpolation=cv2.INTER_LINEAR) for uint8 HWC / HW or float32 HW."""
+    dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
+    if src.dtype == np.uint8:
+        src = np.ascontiguousarray(src)
+        sh, sw = src.shape[:2]
+        cn = 1 if src.ndim == 2 else src.shape[2]
+        dst = np.empty((dh, dw) + src.shape[2:], np.uint8)
+        rc = lib().oracle_resize_linear_u8(_p(src, ctypes.c_uint8), sw, sh, cn, _p(dst, ctypes.c_uint8), dw, dh)
+    else:
+        src = np.ascontiguousarray(src, np.float32)
+        sh, sw = src.shape
+        dst = np.empty((dh, dw), np.float32)
+        rc = lib().oracle_resize_linear_f32(_p(src, ctypes.c_float), sw, sh, _p(dst, ctypes.c_float), dw, dh)
+    if rc:
+        raise ValueError("oracle_resize_linear: bad arguments")
     return dst
 
 

@@ -95,6 +95,11 @@ void oracle_undistort_u8(const uint8_t* src, int w, int h, int cn, const double 
 void oracle_lanczos4_itab(int16_t* tab /* 1024*64 */);
 void oracle_bilinear_itab(int16_t* tab /* 1024*4 */);
 
+/* cv2.resize(src, (dw, dh), interpolation=INTER_LINEAR) as boxx.resize calls it
+ * (stereo_matching.py:62,66): u8 HWC (fixed point) and float32 single channel */
+int oracle_resize_linear_u8(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh);
+int oracle_resize_linear_f32(const float* src, int sw, int sh, float* dst, int dw, int dh);
+
 /* stereo_matching.py:63-69 (identity resize) + stereo_camera.py:510-513,408-413:
  * disp16 (int16 x16) -> disparity f32 (masked, +min_disparity) and rectified depth f64 */
 void oracle_disp_to_depth(const int16_t* disp16, const uint8_t* valid_mask, int w, int h,
