@@ -30,6 +30,7 @@ namespace camd {
 
 static constexpr uint32_t SENT_PK = 0x7fff7fffu;  // MAX_COST in both halves
 static constexpr int MAX_COST = 32767;
+static constexpr int CAMD_MULTI_MAX_BATCH = 4;  // concurrent-direction path keeps npaths volumes per pair
 
 struct Geom {
     int W, H, cn;          // image
@@ -216,11 +217,20 @@ __global__ __launch_bounds__(256) void k_vsum(const uint4* __restrict__ Hs, uint
 // All arithmetic is u16: real values are in [0, 32767], MAX_COST + P1 does not wrap, and the final
 // (C + m) - delta is exact modulo 2^16 (OpenCV's (CostType) cast).
 // ------------------------------------------------------------------------------------------------
+// directions of one launch: blockIdx.z selects the entry; with more than one entry every direction
+// writes its own volume (Sv + z * dir_stride, FIRST only) so that all of them run concurrently
+struct ScanDirs {
+    int dx[8], dy[8], nlines[8];
+    size_t dir_stride;
+};
+
 template <int LANES, int NV, bool FIRST, bool PAD>
-__global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, uint16_t* __restrict__ Sv,
-                                              Geom g, int dx, int dy, int nlines, size_t vol_stride)
+__global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, uint16_t* __restrict__ Sbase,
+                                              Geom g, ScanDirs sd, size_t vol_stride)
 {
     constexpr int NR = 4 * NV;
+    const int dx = sd.dx[blockIdx.z], dy = sd.dy[blockIdx.z], nlines = sd.nlines[blockIdx.z];
+    uint16_t* __restrict__ Sv = Sbase + (size_t)blockIdx.z * sd.dir_stride;
     const int tid = blockIdx.x * 256 + threadIdx.x;
     const int line = tid / LANES, li = tid % LANES;
     if (line >= nlines) return;
@@ -351,7 +361,7 @@ static constexpr uint32_t KEY_INIT = 0x7fff0000u;
 template <int LANES, int NV>
 __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, int16_t* __restrict__ disp,
                                              size_t disp_pitch_e, size_t disp_stride_e, Geom g,
-                                             size_t vol_stride)
+                                             size_t vol_stride, int nvol, size_t dir_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);          // [W]
@@ -377,6 +387,16 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
         for (int v = 0; v < NV; v++) {
             uint4 q = p[v];
             s[4 * v] = q.x; s[4 * v + 1] = q.y; s[4 * v + 2] = q.z; s[4 * v + 3] = q.w;
+        }
+        // concurrent-direction path: S = saturating sum of the per-direction volumes
+        for (int dv = 1; dv < nvol; dv++) {
+            const uint4* pv = reinterpret_cast<const uint4*>(Srow + (size_t)dv * dir_stride + (size_t)x * g.Dp);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                uint4 q = pv[v];
+                s[4 * v] = pk_addsat_i16(s[4 * v], q.x); s[4 * v + 1] = pk_addsat_i16(s[4 * v + 1], q.y);
+                s[4 * v + 2] = pk_addsat_i16(s[4 * v + 2], q.z); s[4 * v + 3] = pk_addsat_i16(s[4 * v + 3], q.w);
+            }
         }
         // (S << 16 | d) minimum: smallest S, then smallest d
         uint32_t key = 0xffffffffu;
@@ -495,6 +515,7 @@ struct camd_sgbm {
     uint32_t *flags, *ticket, *err, *keys;
     int16_t* d1;
     uint32_t epoch;
+    uint16_t* Smulti;     // concurrent-direction path: npaths volumes per pair, allocated on first use
     int last_batch;
     bool profiling;
     hipEvent_t ev[camd::ST_COUNT + 1];
@@ -554,19 +575,30 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ndirs directions in one launch (ndirs > 1 only with FIRST: each direction writes its own volume)
 template <bool FIRST>
-static int launch_scan(const camd_sgbm* h, int dx, int dy, int batch, hipStream_t st)
+static int launch_scan(const camd_sgbm* h, const int (*dirs)[2], int ndirs, uint16_t* S, size_t dir_stride,
+                       int batch, hipStream_t st)
 {
     const Geom& g = h->g;
-    int nlines = dy == 0 ? g.H : (dx == 0 ? g.W1 : g.W1 + g.H - 1);
-    dim3 grid(div_up((long long)nlines * g.lanes, 256), batch);
+    ScanDirs sd;
+    int maxlines = 0;
+    for (int i = 0; i < 8; i++) {
+        int k = i < ndirs ? i : 0;
+        sd.dx[i] = dirs[k][0];
+        sd.dy[i] = dirs[k][1];
+        sd.nlines[i] = sd.dy[i] == 0 ? g.H : (sd.dx[i] == 0 ? g.W1 : g.W1 + g.H - 1);
+        if (i < ndirs && sd.nlines[i] > maxlines) maxlines = sd.nlines[i];
+    }
+    sd.dir_stride = dir_stride;
+    dim3 grid(div_up((long long)maxlines * g.lanes, 256), batch, ndirs);
     const bool pad = g.Dp != g.D;
-#define CAMD_SCAN(LN, NVV)                                                                            \
-    do {                                                                                              \
-        if (pad) hipLaunchKernelGGL((k_scan<LN, NVV, FIRST, true>), grid, dim3(256), 0, st, h->C, h->S, g, \
-                                    dx, dy, nlines, h->vol_elems);                                    \
-        else hipLaunchKernelGGL((k_scan<LN, NVV, FIRST, false>), grid, dim3(256), 0, st, h->C, h->S, g, \
-                                dx, dy, nlines, h->vol_elems);                                        \
+#define CAMD_SCAN(LN, NVV)                                                                                  \
+    do {                                                                                                    \
+        if (pad) hipLaunchKernelGGL((k_scan<LN, NVV, FIRST, true>), grid, dim3(256), 0, st, h->C, S, g, sd, \
+                                    h->vol_elems);                                                          \
+        else hipLaunchKernelGGL((k_scan<LN, NVV, FIRST, false>), grid, dim3(256), 0, st, h->C, S, g, sd,    \
+                                h->vol_elems);                                                              \
     } while (0)
     if (g.lanes == 2) CAMD_SCAN(2, 1);
     else if (g.lanes == 4) CAMD_SCAN(4, 1);
@@ -580,16 +612,16 @@ static int launch_scan(const camd_sgbm* h, int dx, int dy, int batch, hipStream_
     return CAMD_OK;
 }
 
-static int launch_wta(const camd_sgbm* h, int16_t* disp, size_t pitch_e, size_t stride_e, int batch,
-                      hipStream_t st)
+static int launch_wta(const camd_sgbm* h, const uint16_t* S, int nvol, size_t dir_stride, int16_t* disp,
+                      size_t pitch_e, size_t stride_e, int batch, hipStream_t st)
 {
     const Geom& g = h->g;
     dim3 grid(g.H, batch);
     size_t lds = (size_t)g.W * 6;
     lds = align_up(lds, 16);
-#define CAMD_WTA(LN, NVV)                                                                           \
-    hipLaunchKernelGGL((k_wta<LN, NVV>), grid, dim3(256), lds, st, h->S, disp, pitch_e, stride_e, g, \
-                       h->vol_elems)
+#define CAMD_WTA(LN, NVV)                                                                       \
+    hipLaunchKernelGGL((k_wta<LN, NVV>), grid, dim3(256), lds, st, S, disp, pitch_e, stride_e, g, \
+                       h->vol_elems, nvol, dir_stride)
     if (g.lanes == 2) CAMD_WTA(2, 1);
     else if (g.lanes == 4) CAMD_WTA(4, 1);
     else if (g.lanes == 8) CAMD_WTA(8, 1);
@@ -731,7 +763,7 @@ int camd_sgbm_destroy(camd_sgbm* h)
     (void)hipFree(h->C); (void)hipFree(h->S);
     (void)hipFree(h->raw); (void)hipFree(h->speckle_ws);
     (void)hipFree(h->E); (void)hipFree(h->flags); (void)hipFree(h->ticket); (void)hipFree(h->keys);
-    (void)hipFree(h->d1);
+    (void)hipFree(h->d1); (void)hipFree(h->Smulti);
     delete h;
     return CAMD_OK;
 }
@@ -749,7 +781,7 @@ int camd_sgbm_query(const camd_sgbm* h, int* width1, int* D, int* Dp, int* minX1
 int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
 {
     if (!h) { set_error("handle is NULL"); return CAMD_ERR_BAD_ARG; }
-    if (option == CAMD_OPT_PATH && (value == 0 || value == 1)) h->path = value;
+    if (option == CAMD_OPT_PATH && value >= CAMD_PATH_AUTO && value <= CAMD_PATH_CONCURRENT) h->path = value;
     else if (option == CAMD_OPT_KEEP_S) h->keep_S = value != 0;
     else { set_error("unknown option %d / value %d", option, value); return CAMD_ERR_BAD_ARG; }
     return CAMD_OK;
@@ -846,7 +878,26 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         CAMD_LAUNCH_CHECK();
     }
 
-    const bool band = h->band_ok && h->path == 0;
+    // aggregation path: fused band passes win on throughput (>= ~8 pairs per launch), concurrent
+    // per-direction scans on latency (a few pairs: every direction gets its own S volume and all of them
+    // run at once), sequential scans are the generic fallback
+    int path = h->path;
+    if (path == CAMD_PATH_AUTO) {
+        if (batch < 8 && h->max_batch <= CAMD_MULTI_MAX_BATCH) path = CAMD_PATH_CONCURRENT;
+        else if (h->band_ok) path = CAMD_PATH_BAND;
+        else path = CAMD_PATH_SCAN;
+    }
+    if (path == CAMD_PATH_BAND && !h->band_ok) path = CAMD_PATH_SCAN;
+    if (path == CAMD_PATH_CONCURRENT) {
+        if (h->max_batch > CAMD_MULTI_MAX_BATCH) path = CAMD_PATH_SCAN;
+        else if (!h->Smulti) {
+            hipError_t e = hipMalloc((void**)&h->Smulti, (size_t)g.npaths * h->max_batch * h->vol_elems * 2);
+            if (e != hipSuccess) { (void)hipGetLastError(); path = CAMD_PATH_SCAN; }
+        }
+    }
+    const bool band = path == CAMD_PATH_BAND;
+    const bool multi = path == CAMD_PATH_CONCURRENT;
+    const size_t dir_stride = (size_t)h->max_batch * h->vol_elems;
     MARK(ST_SCAN);
     if (band) {
         // fused passes: every pass reads C once and touches S once for up to three directions
@@ -867,10 +918,15 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         if (rc != CAMD_OK) return rc;
     } else {
         static const int dirs[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1}};
-        for (int i = 0; i < g.npaths; i++) {
-            int rc = i == 0 ? launch_scan<true>(h, dirs[i][0], dirs[i][1], batch, st)
-                            : launch_scan<false>(h, dirs[i][0], dirs[i][1], batch, st);
+        if (multi) {
+            int rc = launch_scan<true>(h, dirs, g.npaths, h->Smulti, dir_stride, batch, st);
             if (rc != CAMD_OK) return rc;
+        } else {
+            for (int i = 0; i < g.npaths; i++) {
+                int rc = i == 0 ? launch_scan<true>(h, dirs + i, 1, h->S, 0, batch, st)
+                                : launch_scan<false>(h, dirs + i, 1, h->S, 0, batch, st);
+                if (rc != CAMD_OK) return rc;
+            }
         }
     }
 
@@ -880,7 +936,8 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
                            (size_t)g.W, raw_stride, g);
         CAMD_LAUNCH_CHECK();
     } else {
-        int rc = launch_wta(h, h->raw, (size_t)g.W, raw_stride, batch, st);
+        int rc = multi ? launch_wta(h, h->Smulti, g.npaths, dir_stride, h->raw, (size_t)g.W, raw_stride, batch, st)
+                       : launch_wta(h, h->S, 1, 0, h->raw, (size_t)g.W, raw_stride, batch, st);
         if (rc != CAMD_OK) return rc;
     }
 

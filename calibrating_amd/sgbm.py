@@ -36,8 +36,9 @@ class StereoSGBM:
         self._options = {}
 
     def set_option(self, option, value):
-        """'path': 0 = fused band-wavefront passes (default), 1 = one line-scan launch per direction;
-        'keep_S': 1 = keep the aggregated volume for debug_volume('S') on the fused path."""
+        """'path': 0 = auto (default), 1 = one line-scan launch per direction, 2 = fused band-wavefront
+        passes (throughput), 3 = all directions concurrently (latency, small batches);
+        'keep_S': 1 = keep the aggregated volume for debug_volume('S') on the band path."""
         opt = {"path": 0, "keep_S": 1}[option]
         self._options[opt] = int(value)
         if self._handle is not None:
