@@ -564,6 +564,13 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
                   p->preFilterCap);
         return CAMD_ERR_UNSUPPORTED;
     }
+    if (g->W1 > 0 && g->W1 <= g->SW2) {
+        // cv2's first box sum reads pixel-cost columns 0..SW2 without clamping to width1-1: with fewer
+        // columns than that it reads memory it never wrote, so there is no reference answer to match
+        set_error("only %d matchable columns for blockSize %d: cv2.StereoSGBM's result is undefined there "
+                  "(needs width - numDisparities > blockSize / 2)", g->W1, bs);
+        return CAMD_ERR_UNSUPPORTED;
+    }
     if (g->D > 512) { set_error("numDisparities %d > 512 not implemented", g->D); return CAMD_ERR_UNSUPPORTED; }
     if (g->D > 64) { g->lanes = 16; g->nv = (g->D + 127) / 128; }
     else if (g->D > 32) { g->lanes = 8; g->nv = 1; }

@@ -174,6 +174,9 @@ static int compute_disparity_sgbm(const PixType* img1, const PixType* img2, int 
         for (size_t i = 0; i < (size_t)width * height; i++) disp1[i] = (DispType)INVALID_DISP_SCALED;
         return 0;
     }
+    /* The first box sum below reads pixDiff columns 0..SW2 unclamped (as cv2 does): with width1 <= SW2 cv2
+     * reads memory it never wrote, so no reference answer exists -- refuse instead of over-reading. */
+    if (width1 <= SW2) return -2;
 
     /* buffers (BufferSGBM) */
     const int NR = 4;            /* directions per pass */

@@ -233,3 +233,11 @@ def test_golden_fixtures(oracle):
     assert np.array_equal(oracle.remap_u8(r["src"], r["mapx"], r["mapy"], 4), r["lanczos4"])
     assert np.array_equal(oracle.remap_u8(r["src"], r["mapx"], r["mapy"], 1), r["linear"])
     assert np.array_equal(oracle.lanczos4_itab(), r["lanczos4_itab"])
+
+
+def test_oracle_refuses_undefined_narrow_case(oracle):
+    """0 < width1 <= blockSize/2: cv2's first box sum reads columns it never computed -> no defined answer."""
+    img = np.zeros((12, 66), np.uint8)
+    with pytest.raises(ValueError):
+        oracle.sgbm_compute(img, img, numDisparities=64, blockSize=5)
+    assert oracle.sgbm_compute(img, img, numDisparities=64, blockSize=3).shape == (12, 66)
