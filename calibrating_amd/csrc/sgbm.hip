@@ -186,27 +186,55 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
 
 // ------------------------------------------------------------------------------------------------
 // k_vsum: C[y][x][d] = P2 + sum_{dy=-SH2..SH2} Hs[clamp(y+dy,0,H-1)][x][d]   (u16 wrap)
-// One thread = 8 consecutive d (16 bytes).
+// One thread = 8 consecutive d (16 bytes) of one column, walking VSUM_ROWS rows downwards with a running
+// sum: C(y) = C(y-1) + Hs(y+SH2) - Hs(y-SH2-1).  The K = 2*SH2+1 rows inside the window live in a
+// thread-private LDS ring, so every Hs row is read once per row segment (plus K-1 halo rows) whatever the
+// row pitch is -- a per-row kernel that re-reads its K rows only gets them from L2 when vertically
+// adjacent workgroups happen to land on the same XCD (true for W1 = 1792, false for W1 = 1793).
 // ------------------------------------------------------------------------------------------------
+static constexpr int VSUM_ROWS = 64;
+
 __global__ __launch_bounds__(256) void k_vsum(const uint4* __restrict__ Hs, uint4* __restrict__ C, Geom g,
                                               size_t vol_stride16)
 {
+    extern __shared__ uint4 vring[];  // [K][256]
     const size_t rowv = (size_t)g.W1 * (g.Dp / 8);  // uint4 per row
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rowv) return;
-    const int y = blockIdx.y, pair = blockIdx.z;
-    const uint4* base = Hs + (size_t)pair * vol_stride16;
-    uint32_t p2 = dup16((uint32_t)g.P2);
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i0 < rowv;
+    const size_t i = ok ? i0 : rowv - 1;
+    const int pair = blockIdx.z, H = g.H, SH2 = g.SW2, K = 2 * SH2 + 1;
+    const int y0 = blockIdx.y * VSUM_ROWS, y1 = min(y0 + VSUM_ROWS, H);
+    const uint4* base = Hs + (size_t)pair * vol_stride16 + i;
+    uint4* out = C + (size_t)pair * vol_stride16 + i;
+    auto ld = [&](int yy) -> uint4 { return base[(size_t)min(max(yy, 0), H - 1) * rowv]; };
+    const uint32_t p2 = dup16((uint32_t)g.P2);
     uint4 acc = make_uint4(p2, p2, p2, p2);
-    for (int dy = -g.SW2; dy <= g.SW2; dy++) {
-        int yy = min(max(y + dy, 0), g.H - 1);
-        uint4 v = base[(size_t)yy * rowv + i];
-        acc.x = pk_add_u16(acc.x, v.x);
-        acc.y = pk_add_u16(acc.y, v.y);
-        acc.z = pk_add_u16(acc.z, v.z);
-        acc.w = pk_add_u16(acc.w, v.w);
+    for (int j = 0; j < K; j++) {
+        uint4 v = ld(y0 - SH2 + j);
+        vring[j * 256 + threadIdx.x] = v;
+        acc.x = pk_add_u16(acc.x, v.x); acc.y = pk_add_u16(acc.y, v.y);
+        acc.z = pk_add_u16(acc.z, v.z); acc.w = pk_add_u16(acc.w, v.w);
     }
-    C[(size_t)pair * vol_stride16 + (size_t)y * rowv + i] = acc;
+    if (ok) out[(size_t)y0 * rowv] = acc;
+    int slot = 0;  // ring position of the oldest row (y - SH2 - 1 of the next output row)
+    uint4 nx[4];   // rows y+SH2 .. y+3+SH2 in flight
+#pragma unroll
+    for (int u = 0; u < 4; u++) nx[u] = ld(y0 + 1 + u + SH2);
+    for (int y = y0 + 1; y < y1; y += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (y + u < y1) {
+                const uint4 v = nx[u];
+                nx[u] = ld(y + u + 4 + SH2);
+                const uint4 o = vring[slot * 256 + threadIdx.x];
+                vring[slot * 256 + threadIdx.x] = v;
+                slot = slot + 1 == K ? 0 : slot + 1;
+                acc.x = pk_sub_u16(pk_add_u16(acc.x, v.x), o.x); acc.y = pk_sub_u16(pk_add_u16(acc.y, v.y), o.y);
+                acc.z = pk_sub_u16(pk_add_u16(acc.z, v.z), o.z); acc.w = pk_sub_u16(pk_add_u16(acc.w, v.w), o.w);
+                if (ok) out[(size_t)(y + u) * rowv] = acc;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -480,6 +508,7 @@ __global__ void k_fill_s16(int16_t* p, size_t pitch_e, size_t stride_e, int W, i
 
 }  // namespace camd
 #include "sgbm_band.hpp"
+#include "sgbm_band4.hpp"
 namespace camd {
 
 // defined in post.hip
@@ -679,6 +708,42 @@ static int launch_band(camd_sgbm* h, int sx, int sy, int dirs, int mode, int bat
     return CAMD_OK;
 }
 
+// four-direction pass (full = true: H, V, Dg, A of sweep (sx, sy)) or the row-parallel H-only pass (sgbm_band4.hpp)
+static int launch_band4(camd_sgbm* h, int sx, int sy, bool full, int mode, int batch, hipStream_t st)
+{
+    const Geom& g = h->g;
+    BandArgs a;
+    a.C = h->C; a.S = h->S; a.E = h->E; a.flags = h->flags; a.ticket = h->ticket; a.err = h->err;
+    a.keys = h->keys; a.d1 = h->d1; a.vol_stride = h->vol_elems; a.erec_stride = h->erec_stride;
+    a.sx = sx; a.sy = sy; a.nbands = h->nbands; a.nchunks = h->nchunks; a.npairs = batch;
+    a.epoch = ++h->epoch;
+    a.write_S = h->keep_S;
+    static const int nodep = getenv("CAMD_BAND_NODEP") ? atoi(getenv("CAMD_BAND_NODEP")) : 0;
+    a.nodep = nodep;
+    CAMD_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
+    dim3 grid(h->nbands * batch), block(BAND_BLOCK);
+    const bool pad = g.Dp != g.D;
+#define CAMD_BAND4(LN, NVV, FF, MM)                                                               \
+    do {                                                                                          \
+        if (pad) hipLaunchKernelGGL((k_band4<LN, NVV, FF, MM, true>), grid, block, 0, st, a, g);  \
+        else hipLaunchKernelGGL((k_band4<LN, NVV, FF, MM, false>), grid, block, 0, st, a, g);     \
+    } while (0)
+#define CAMD_BAND4_SHAPE(FF, MM)                                   \
+    do {                                                           \
+        if (g.lanes == 16 && g.nv == 1) CAMD_BAND4(16, 1, FF, MM); \
+        else if (g.lanes == 16) CAMD_BAND4(16, 2, FF, MM);         \
+        else CAMD_BAND4(8, 1, FF, MM);                             \
+    } while (0)
+    if (full && mode == 0) CAMD_BAND4_SHAPE(true, 0);
+    else if (full && mode == 2) CAMD_BAND4_SHAPE(true, 2);
+    else if (!full && mode == 2) CAMD_BAND4_SHAPE(false, 2);
+    else { set_error("band pass (full %d, mode %d) not instantiated", (int)full, mode); return CAMD_ERR_UNSUPPORTED; }
+#undef CAMD_BAND4_SHAPE
+#undef CAMD_BAND4
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
 }  // namespace camd
 
 using namespace camd;
@@ -699,7 +764,7 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     if (band_ok) {
         const int R = BAND_THREADS / g.lanes;
         size_t nb = (size_t)div_up(height, R);
-        total += (size_t)max_batch * nb * ((size_t)g.W1 * g.lanes * (4 * g.nv + 1) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
+        total += (size_t)max_batch * nb * (band4_erec_stride(g.W1, g.lanes, g.nv) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
         total += (size_t)max_batch * height * width * 6 + 8;
     }
     return total;
@@ -741,7 +806,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         const int R = BAND_THREADS / g.lanes;
         h->nbands = div_up(height, R);
         h->nchunks = div_up(g.W1, BAND_CHUNK);
-        h->erec_stride = (size_t)g.W1 * g.lanes * (4 * g.nv + 1);
+        h->erec_stride = band4_erec_stride(g.W1, g.lanes, g.nv);  // >= the 3-direction layout's
         size_t nflags = (size_t)max_batch * h->nbands * h->nchunks;
         size_t npix = (size_t)max_batch * height * width;
         if (e == hipSuccess) e = hipMalloc((void**)&h->E, (size_t)max_batch * h->nbands * h->erec_stride * 8);
@@ -879,7 +944,8 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     MARK(ST_VSUM);
     {
         size_t rowv = (size_t)g.W1 * (g.Dp / 8);
-        hipLaunchKernelGGL(k_vsum, dim3(div_up((long long)rowv, 256), g.H, batch), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_vsum, dim3(div_up((long long)rowv, 256), div_up(g.H, VSUM_ROWS), batch), dim3(256),
+                           (size_t)(2 * g.SW2 + 1) * 256 * sizeof(uint4), st,
                            reinterpret_cast<const uint4*>(h->S), reinterpret_cast<uint4*>(h->C), g,
                            h->vol_elems / 8);
         CAMD_LAUNCH_CHECK();
@@ -913,14 +979,22 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
                            (g.minD - 1) * 16);
         CAMD_LAUNCH_CHECK();
         int rc;
-        if (g.mode == CAMD_MODE_HH) {
-            rc = launch_band(h, +1, +1, 7, 0, batch, st);                 // ->  v  \.
-            if (rc == CAMD_OK) rc = launch_band(h, -1, -1, 7, 1, batch, st);  // <-  ^  \^
-            if (rc == CAMD_OK) rc = launch_band(h, -1, +1, 4, 1, batch, st);  // ./
-            if (rc == CAMD_OK) rc = launch_band(h, +1, -1, 4, 2, batch, st);  // /^ + WTA
+        static const bool band3 = getenv("CAMD_BAND3") && atoi(getenv("CAMD_BAND3"));  // A/B: 3-direction passes
+        if (band3) {
+            if (g.mode == CAMD_MODE_HH) {
+                rc = launch_band(h, +1, +1, 7, 0, batch, st);                     // ->  v  \.
+                if (rc == CAMD_OK) rc = launch_band(h, -1, -1, 7, 1, batch, st);  // <-  ^  \^
+                if (rc == CAMD_OK) rc = launch_band(h, -1, +1, 4, 1, batch, st);  // ./
+                if (rc == CAMD_OK) rc = launch_band(h, +1, -1, 4, 2, batch, st);  // /^ + WTA
+            } else {
+                rc = launch_band(h, +1, +1, 7, 0, batch, st);                     // ->  v  \.
+                if (rc == CAMD_OK) rc = launch_band(h, -1, +1, 5, 2, batch, st);  // <-  ./ + WTA
+            }
         } else {
-            rc = launch_band(h, +1, +1, 7, 0, batch, st);                 // ->  v  \.
-            if (rc == CAMD_OK) rc = launch_band(h, -1, +1, 5, 2, batch, st);  // <-  ./ + WTA
+            rc = launch_band4(h, +1, +1, true, 0, batch, st);                                  // ->  v  \.  ./
+            if (rc == CAMD_OK)
+                rc = g.mode == CAMD_MODE_HH ? launch_band4(h, -1, -1, true, 2, batch, st)      // <-  ^  \^  /^ + WTA
+                                            : launch_band4(h, -1, +1, false, 2, batch, st);    // <- + WTA
         }
         if (rc != CAMD_OK) return rc;
     } else {
