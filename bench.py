@@ -191,10 +191,10 @@ def main():
         gpu_ms_step = sum(stage_ms.values()) / a.steps
         achieved = b_alg * nb / (gpu_ms_step * 1e-3) / 1e9
         if a.path == 0:
-            # fused band passes: C read once per pass; S written (first), read+written (middle), read (last)
-            npass = 4 if a.mode == "hh" else 2
-            vols = 10 if a.mode == "hh" else 4
-            kname = "k_band (fused aggregation pass: up to 3 directions, last pass + WTA)"
+            # fused band passes (both modes): pass 1 reads C, writes S; pass 2 reads C and S (+ WTA)
+            npass = 2
+            vols = 4
+            kname = "k_band (fused aggregation pass: four directions, last pass + WTA)"
         else:
             npass = 8 if a.mode == "hh" else 5
             vols = 3 * npass - 1

@@ -11,7 +11,7 @@
 //                  16-bit VALU ops; one wave = 64 consecutive disparities, lane j reads the right-image
 //                  entry of column x - d with ds_read_b128, the left entry is an LDS broadcast
 //   k_vsum         vertical box sum + P2  ->  C[y][x][d]  (int16, d fastest)
-//   k_band         (sgbm_band.hpp) fused aggregation: up to three directions per pass + WTA in the last
+//   k_band         (sgbm_band.hpp) fused aggregation: four directions per pass + WTA in the last
 //   k_scan         one aggregation direction as independent line scans from a zero border state;
 //                  a line is owned by a 2..16-lane group (8*NV disparities per lane, packed u16x2),
 //                  neighbours d-1 / d+1 by DPP row shifts, min over d by a DPP butterfly
@@ -508,7 +508,6 @@ __global__ void k_fill_s16(int16_t* p, size_t pitch_e, size_t stride_e, int W, i
 
 }  // namespace camd
 #include "sgbm_band.hpp"
-#include "sgbm_band4.hpp"
 namespace camd {
 
 // defined in post.hip
@@ -670,8 +669,9 @@ static int launch_wta(const camd_sgbm* h, const uint16_t* S, int nvol, size_t di
     return CAMD_OK;
 }
 
-// one band-wavefront pass over `batch` pairs: directions DIRS (bit0 H, bit1 V, bit2 Dg) of sweep (sx, sy)
-static int launch_band(camd_sgbm* h, int sx, int sy, int dirs, int mode, int batch, hipStream_t st)
+// one band-wavefront pass over `batch` pairs (sgbm_band.hpp): full = H, V, Dg, A of sweep (sx, sy);
+// !full = the row-parallel H-only pass
+static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int batch, hipStream_t st)
 {
     const Geom& g = h->g;
     BandArgs a;
@@ -685,61 +685,23 @@ static int launch_band(camd_sgbm* h, int sx, int sy, int dirs, int mode, int bat
     CAMD_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
     dim3 grid(h->nbands * batch), block(BAND_BLOCK);
     const bool pad = g.Dp != g.D;
-#define CAMD_BAND(LN, NVV, DD, MM)                                                                \
+#define CAMD_BAND(LN, NVV, FF, MM)                                                               \
     do {                                                                                          \
-        if (pad) hipLaunchKernelGGL((k_band<LN, NVV, DD, MM, true>), grid, block, 0, st, a, g);   \
-        else hipLaunchKernelGGL((k_band<LN, NVV, DD, MM, false>), grid, block, 0, st, a, g);      \
+        if (pad) hipLaunchKernelGGL((k_band<LN, NVV, FF, MM, true>), grid, block, 0, st, a, g);  \
+        else hipLaunchKernelGGL((k_band<LN, NVV, FF, MM, false>), grid, block, 0, st, a, g);     \
     } while (0)
-#define CAMD_BAND_SHAPE(DD, MM)                                   \
-    do {                                                          \
-        if (g.lanes == 16 && g.nv == 1) CAMD_BAND(16, 1, DD, MM); \
-        else if (g.lanes == 16) CAMD_BAND(16, 2, DD, MM);         \
-        else CAMD_BAND(8, 1, DD, MM);                             \
+#define CAMD_BAND_SHAPE(FF, MM)                                   \
+    do {                                                           \
+        if (g.lanes == 16 && g.nv == 1) CAMD_BAND(16, 1, FF, MM); \
+        else if (g.lanes == 16) CAMD_BAND(16, 2, FF, MM);         \
+        else CAMD_BAND(8, 1, FF, MM);                             \
     } while (0)
-    if (dirs == 7 && mode == 0) CAMD_BAND_SHAPE(7, 0);
-    else if (dirs == 7 && mode == 1) CAMD_BAND_SHAPE(7, 1);
-    else if (dirs == 5 && mode == 2) CAMD_BAND_SHAPE(5, 2);
-    else if (dirs == 4 && mode == 1) CAMD_BAND_SHAPE(4, 1);
-    else if (dirs == 4 && mode == 2) CAMD_BAND_SHAPE(4, 2);
-    else { set_error("band pass (%d, %d) not instantiated", dirs, mode); return CAMD_ERR_UNSUPPORTED; }
+    if (full && mode == 0) CAMD_BAND_SHAPE(true, 0);
+    else if (full && mode == 2) CAMD_BAND_SHAPE(true, 2);
+    else if (!full && mode == 2) CAMD_BAND_SHAPE(false, 2);
+    else { set_error("band pass (full %d, mode %d) not instantiated", (int)full, mode); return CAMD_ERR_UNSUPPORTED; }
 #undef CAMD_BAND_SHAPE
 #undef CAMD_BAND
-    CAMD_LAUNCH_CHECK();
-    return CAMD_OK;
-}
-
-// four-direction pass (full = true: H, V, Dg, A of sweep (sx, sy)) or the row-parallel H-only pass (sgbm_band4.hpp)
-static int launch_band4(camd_sgbm* h, int sx, int sy, bool full, int mode, int batch, hipStream_t st)
-{
-    const Geom& g = h->g;
-    BandArgs a;
-    a.C = h->C; a.S = h->S; a.E = h->E; a.flags = h->flags; a.ticket = h->ticket; a.err = h->err;
-    a.keys = h->keys; a.d1 = h->d1; a.vol_stride = h->vol_elems; a.erec_stride = h->erec_stride;
-    a.sx = sx; a.sy = sy; a.nbands = h->nbands; a.nchunks = h->nchunks; a.npairs = batch;
-    a.epoch = ++h->epoch;
-    a.write_S = h->keep_S;
-    static const int nodep = getenv("CAMD_BAND_NODEP") ? atoi(getenv("CAMD_BAND_NODEP")) : 0;
-    a.nodep = nodep;
-    CAMD_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
-    dim3 grid(h->nbands * batch), block(BAND_BLOCK);
-    const bool pad = g.Dp != g.D;
-#define CAMD_BAND4(LN, NVV, FF, MM)                                                               \
-    do {                                                                                          \
-        if (pad) hipLaunchKernelGGL((k_band4<LN, NVV, FF, MM, true>), grid, block, 0, st, a, g);  \
-        else hipLaunchKernelGGL((k_band4<LN, NVV, FF, MM, false>), grid, block, 0, st, a, g);     \
-    } while (0)
-#define CAMD_BAND4_SHAPE(FF, MM)                                   \
-    do {                                                           \
-        if (g.lanes == 16 && g.nv == 1) CAMD_BAND4(16, 1, FF, MM); \
-        else if (g.lanes == 16) CAMD_BAND4(16, 2, FF, MM);         \
-        else CAMD_BAND4(8, 1, FF, MM);                             \
-    } while (0)
-    if (full && mode == 0) CAMD_BAND4_SHAPE(true, 0);
-    else if (full && mode == 2) CAMD_BAND4_SHAPE(true, 2);
-    else if (!full && mode == 2) CAMD_BAND4_SHAPE(false, 2);
-    else { set_error("band pass (full %d, mode %d) not instantiated", (int)full, mode); return CAMD_ERR_UNSUPPORTED; }
-#undef CAMD_BAND4_SHAPE
-#undef CAMD_BAND4
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
 }
@@ -764,7 +726,7 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     if (band_ok) {
         const int R = BAND_THREADS / g.lanes;
         size_t nb = (size_t)div_up(height, R);
-        total += (size_t)max_batch * nb * (band4_erec_stride(g.W1, g.lanes, g.nv) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
+        total += (size_t)max_batch * nb * (band_erec_stride(g.W1, g.lanes, g.nv) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
         total += (size_t)max_batch * height * width * 6 + 8;
     }
     return total;
@@ -806,7 +768,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         const int R = BAND_THREADS / g.lanes;
         h->nbands = div_up(height, R);
         h->nchunks = div_up(g.W1, BAND_CHUNK);
-        h->erec_stride = band4_erec_stride(g.W1, g.lanes, g.nv);  // >= the 3-direction layout's
+        h->erec_stride = band_erec_stride(g.W1, g.lanes, g.nv);
         size_t nflags = (size_t)max_batch * h->nbands * h->nchunks;
         size_t npix = (size_t)max_batch * height * width;
         if (e == hipSuccess) e = hipMalloc((void**)&h->E, (size_t)max_batch * h->nbands * h->erec_stride * 8);
@@ -973,29 +935,16 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     const size_t dir_stride = (size_t)h->max_batch * h->vol_elems;
     MARK(ST_SCAN);
     if (band) {
-        // fused passes: every pass reads C once and touches S once for up to three directions
+        // fused passes: every pass reads C once and touches S once for up to four directions
         size_t npix = (size_t)batch * g.H * g.W;
         hipLaunchKernelGGL(k_wta_init, dim3(div_up((long long)npix, 256)), dim3(256), 0, st, h->keys, h->d1, npix,
                            (g.minD - 1) * 16);
         CAMD_LAUNCH_CHECK();
         int rc;
-        static const bool band3 = getenv("CAMD_BAND3") && atoi(getenv("CAMD_BAND3"));  // A/B: 3-direction passes
-        if (band3) {
-            if (g.mode == CAMD_MODE_HH) {
-                rc = launch_band(h, +1, +1, 7, 0, batch, st);                     // ->  v  \.
-                if (rc == CAMD_OK) rc = launch_band(h, -1, -1, 7, 1, batch, st);  // <-  ^  \^
-                if (rc == CAMD_OK) rc = launch_band(h, -1, +1, 4, 1, batch, st);  // ./
-                if (rc == CAMD_OK) rc = launch_band(h, +1, -1, 4, 2, batch, st);  // /^ + WTA
-            } else {
-                rc = launch_band(h, +1, +1, 7, 0, batch, st);                     // ->  v  \.
-                if (rc == CAMD_OK) rc = launch_band(h, -1, +1, 5, 2, batch, st);  // <-  ./ + WTA
-            }
-        } else {
-            rc = launch_band4(h, +1, +1, true, 0, batch, st);                                  // ->  v  \.  ./
-            if (rc == CAMD_OK)
-                rc = g.mode == CAMD_MODE_HH ? launch_band4(h, -1, -1, true, 2, batch, st)      // <-  ^  \^  /^ + WTA
-                                            : launch_band4(h, -1, +1, false, 2, batch, st);    // <- + WTA
-        }
+        rc = launch_band(h, +1, +1, true, 0, batch, st);                                  // ->  v  \.  ./
+        if (rc == CAMD_OK)
+            rc = g.mode == CAMD_MODE_HH ? launch_band(h, -1, -1, true, 2, batch, st)      // <-  ^  \^  /^ + WTA
+                                        : launch_band(h, -1, +1, false, 2, batch, st);    // <- + WTA
         if (rc != CAMD_OK) return rc;
     } else {
         static const int dirs[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1}};
