@@ -41,6 +41,8 @@ def _check(oracle, left, right, p, paths=(2, 1, 3)):
     (24, 300, 128, 3, 11, 0, 0),   # large block
     (20, 400, 300, 1, 5, 0, 1),    # D = 300: three vectors per lane, band path not instantiated -> scans
     (16, 700, 512, 1, 3, 0, 0),    # maximum supported D
+    (12, 640, 512, 3, 11, 0, 1),   # maximum D with a large block: > 64 KB of dynamic LDS in the cost kernel
+    (12, 400, 256, 1, 15, 0, 0),   # largest supported block
     (33, 180, 96, 1, 5, -40, 1),   # negative minDisparity
     (33, 180, 96, 3, 5, 17, 0),    # large positive minDisparity
     (65, 143, 72, 1, 7, 3, 1),     # everything odd
