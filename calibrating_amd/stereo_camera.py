@@ -337,3 +337,35 @@ class Stereo:
         if was_np:
             result = {k: v.cpu().numpy() if isinstance(v, torch.Tensor) else v for k, v in result.items()}
         return result
+
+    def get_depth_batch(self, imgs1, imgs2, return_unrectify_depth=True):
+        """``get_depth`` for ``n`` pairs of the same rig at once: ``imgs1`` / ``imgs2`` are ``(n, h, w, 3)``
+        uint8 (NumPy or torch CUDA), every value of the returned dict carries the leading ``n``.
+
+        Not in the reference (its ``get_depth`` takes one pair, stereo_camera.py:491-533); this is the
+        throughput form of the same stages -- each kernel is launched once for the whole batch, which is
+        what keeps small images (VGA) from being launch-bound.  Pair ``i`` of the result is bit-identical
+        to ``get_depth(imgs1[i], imgs2[i])``.  Requires the SGBM plugin without downsizing.
+        """
+        import torch
+        assert hasattr(self, "stereo_matching"), "Please stereo.set_stereo_matching(stereo_matching)"
+        i1, was_np = self._to_dev(imgs1)
+        i2, _ = self._to_dev(imgs2)
+        if i1.dim() != 4 or i1.shape != i2.shape:
+            raise ValueError("imgs1 / imgs2 must be (n, h, w, c) arrays of equal shape")
+        sm = self.stereo_matching
+        if not (isinstance(sm, SemiGlobalBlockMatching) and min(sm.max_size / max(i1.shape[1:3]), 1) == 1):
+            raise ValueError("get_depth_batch needs a SemiGlobalBlockMatching plugin with max_size >= image size")
+        rectify_img1, rectify_img2 = self.rectify(i1, i2)
+        tb = self._tables(i1.device)
+        disp16 = sm.stereo_sgbm.compute(rectify_img1, rectify_img2)
+        disparity, rectify_depth = imgproc.disp_to_depth(
+            disp16, tb["mask"], sm.stereo_sgbm.getMinDisparity(), self.min_disparity,
+            bool(getattr(self, "translation_rectify_img")), 1.0 * self.baseline * self.K[0, 0], self.get_max_depth())
+        result = dict(rectify_img1=rectify_img1, rectify_depth=rectify_depth, disparity=disparity,
+                      rectify_img2=rectify_img2)
+        if return_unrectify_depth:
+            result.update(unrectify_depth=self.unrectify_depth(rectify_depth), undistort_img1=self.undistort_img(i1))
+        if was_np:
+            result = {k: v.cpu().numpy() if isinstance(v, torch.Tensor) else v for k, v in result.items()}
+        return result

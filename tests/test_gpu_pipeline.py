@@ -191,3 +191,22 @@ def test_get_depth_requires_matcher():
         stereo.get_depth(np.zeros((48, 64, 3), np.uint8), np.zeros((48, 64, 3), np.uint8))
     with pytest.raises(NotImplementedError):
         ca.MetaStereoMatching()(None, None)
+
+
+def test_get_depth_batch_matches_per_pair():
+    """The batched throughput form returns, pair by pair, exactly what get_depth returns."""
+    W, H = 320, 240
+    stereo = ca.Stereo.load(synthetic.rig(W, H))
+    cfg = dict(max_size=W, minDisparity=0, numDisparities=64, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+               uniquenessRatio=10, speckleWindowSize=50, speckleRange=2)
+    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=3.5)
+    pairs = [synthetic.scene_pair(s, W, H, 3) for s in (1, 2, 3, 4, 5)]
+    I1 = np.stack([p[0] for p in pairs]); I2 = np.stack([p[1] for p in pairs])
+    got = stereo.get_depth_batch(I1, I2)
+    for i, (a, b) in enumerate(pairs):
+        ref = stereo.get_depth(a, b)
+        assert set(ref) == set(got)
+        for k in ref:
+            assert np.array_equal(got[k][i], ref[k], equal_nan=True), (i, k)
+    with pytest.raises(ValueError):
+        stereo.get_depth_batch(I1[0], I2[0])

@@ -46,6 +46,14 @@ dt = timeit(lambda: stereo.get_depth(t1, t2), reps=20, warm=3)
 res["C5_vga_d64_get_depth_device_resident_pairs_per_s"] = 1 / dt
 dt = timeit(lambda: stereo.get_depth(i1, i2), reps=20, warm=3)
 res["C5_vga_d64_get_depth_numpy_in_out_pairs_per_s"] = 1 / dt
+# the same stages for 128 pairs per call (Stereo.get_depth_batch): every kernel launched once per batch
+nb = 128
+pairs = [synthetic.scene_pair(100 + i, W, H, 3) for i in range(8)]
+B1 = torch.from_numpy(np.stack([pairs[i % 8][0] for i in range(nb)])).to(dev)
+B2 = torch.from_numpy(np.stack([pairs[i % 8][1] for i in range(nb)])).to(dev)
+dt = timeit(lambda: stereo.get_depth_batch(B1, B2), reps=5, warm=2)
+res["C5_vga_d64_get_depth_batch128_device_resident_pairs_per_s"] = nb / dt
+del B1, B2
 # SGBM-only batch at VGA
 P = {k: v for k, v in cfg.items() if k != "max_size"}
 P["speckleWindowSize"] = 0
