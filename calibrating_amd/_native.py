@@ -64,6 +64,9 @@ SIGNATURES = {
                                              c_void_p, c_void_p, c_int, c_int, c_size_t, c_size_t, c_int,
                                              c_void_p]),
     "camd_undistort_maps_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "camd_init_undistort_rectify_map": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                                c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "camd_undistort_maps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "camd_lanczos4_table_host": (c_int, [c_void_p]),
     "camd_bilinear_table_host": (c_int, [c_void_p]),
     "camd_resize_linear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -60,6 +60,53 @@ def remap(src, mapx, mapy, interpolation=INTER_LANCZOS4, x_shift=0):
     return dst.cpu().numpy() if was_np else dst
 
 
+def _dist_args(D):
+    D = np.zeros(0) if D is None else np.ascontiguousarray(D, np.float64).reshape(-1)
+    return D, (D.ctypes.data if D.size else None), int(D.size)
+
+
+def init_undistort_rectify_map(A, dist, R, Anew, size, valid_for=None, device=None):
+    """cv2.initUndistortRectifyMap(A, dist, R, Anew, size, CV_32FC1) built on the GPU
+    (stereo_camera.py:159-165, utils.py:184-191): returns (mapx, mapy) float32 CUDA tensors (h, w), plus
+    the uint8 valid mask of stereo_camera.py:167-176 when ``valid_for=(src_w, src_h)`` is given."""
+    import torch
+    _native.require_device()
+    w, h = int(size[0]), int(size[1])
+    A = np.ascontiguousarray(A, np.float64).reshape(9)
+    Anew = np.ascontiguousarray(np.asarray(Anew, np.float64)[:, :3]).reshape(9)
+    Rm = None if R is None else np.ascontiguousarray(R, np.float64).reshape(9)
+    D, dptr, nd = _dist_args(dist)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    mapx = torch.empty((h, w), dtype=torch.float32, device=dev)
+    mapy = torch.empty((h, w), dtype=torch.float32, device=dev)
+    mask = torch.empty((h, w), dtype=torch.uint8, device=dev) if valid_for is not None else None
+    sw, sh = (int(valid_for[0]), int(valid_for[1])) if valid_for is not None else (0, 0)
+    with torch.cuda.device(dev):
+        rc = _native.lib().camd_init_undistort_rectify_map(
+            A.ctypes.data, dptr, nd, None if Rm is None else Rm.ctypes.data, Anew.ctypes.data, w, h,
+            mapx.data_ptr(), mapy.data_ptr(), None if mask is None else mask.data_ptr(), sw, sh,
+            _native.current_stream())
+    _native.check(rc, "init_undistort_rectify_map")
+    return (mapx, mapy) if mask is None else (mapx, mapy, mask)
+
+
+def undistort_maps_device(K, D, size, device=None):
+    """The CV_16SC2 + CV_16UC1 maps of cv2.undistort, built on the GPU: (mapxy int16 (h,w,2), mapa int16 view)."""
+    import torch
+    _native.require_device()
+    w, h = int(size[0]), int(size[1])
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    D, dptr, nd = _dist_args(D)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    mxy = torch.empty((h, w, 2), dtype=torch.int16, device=dev)
+    ma = torch.empty((h, w), dtype=torch.int16, device=dev)  # uint16 bit patterns (torch has no uint16 arithmetic)
+    with torch.cuda.device(dev):
+        rc = _native.lib().camd_undistort_maps(K.ctypes.data, dptr, nd, w, h, mxy.data_ptr(), ma.data_ptr(),
+                                               _native.current_stream())
+    _native.check(rc, "undistort_maps")
+    return mxy, ma
+
+
 def undistort_maps(K, D, size):
     """The CV_16SC2 + CV_16UC1 maps cv2.undistort(img, K, D) builds internally (host, init time)."""
     w, h = int(size[0]), int(size[1])

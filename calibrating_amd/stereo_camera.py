@@ -75,17 +75,32 @@ class Stereo:
             center = (center1 + center2) / 2
             self.K[:2, 2] = np.array(xy) / 2 - center
 
-        self.undistort_rectify_map1 = geometry.init_undistort_rectify_map(
-            self.cam1.K, self.cam1.D, self.R1, self.K, xy)
-        self.undistort_rectify_map2 = geometry.init_undistort_rectify_map(
-            self.cam2.K, self.cam2.D, self.R2, self.K, xy)
+        # The maps themselves are built on the GPU when a stage first needs them (_tables); the host copies
+        # (undistort_rectify_map1/2, rectify_valid_mask1: public attributes in the reference) are lazy.
+        for k in ("_map1", "_map2", "_mask1", "_unrectify_depth_maps"):
+            self.__dict__.pop(k, None)
+        self._dev = {}  # device tables, built lazily per device
 
-        def valid_mask_from_remap(mapx, mapy, x, y):
-            return (-0.5 < mapx) & (mapx < x - 0.5) & (-0.5 < mapy) & (mapy < y - 0.5)
+    # host views of the tables, computed on first access (NumPy, float64 internally)
+    @property
+    def undistort_rectify_map1(self):
+        if "_map1" not in self.__dict__:
+            self._map1 = geometry.init_undistort_rectify_map(self.cam1.K, self.cam1.D, self.R1, self.K, self.xy)
+        return self._map1
 
-        self.rectify_valid_mask1 = valid_mask_from_remap(*self.undistort_rectify_map1, *self.cam1.xy)
-        self._dev = {}  # device copies of the tables, built lazily per device
-        self.__dict__.pop("_unrectify_depth_maps", None)
+    @property
+    def undistort_rectify_map2(self):
+        if "_map2" not in self.__dict__:
+            self._map2 = geometry.init_undistort_rectify_map(self.cam2.K, self.cam2.D, self.R2, self.K, self.xy)
+        return self._map2
+
+    @property
+    def rectify_valid_mask1(self):
+        if "_mask1" not in self.__dict__:
+            mapx, mapy = self.undistort_rectify_map1
+            x, y = self.cam1.xy
+            self._mask1 = (-0.5 < mapx) & (mapx < x - 0.5) & (-0.5 < mapy) & (mapy < y - 0.5)
+        return self._mask1
 
     def stereo_recitfy(self):
         axes_z = np.array([0, 0, 1.0])
@@ -101,15 +116,15 @@ class Stereo:
         self.R1 = self.R2 @ self.R[:3, :3]
 
     def _tables(self, device):
-        """Device-resident tables of this rig: {map1x, map1y, map2x, map2y, mask}."""
-        import torch
+        """Device-resident tables of this rig: {map1x, map1y, map2x, map2y, mask}, built by the GPU kernel
+        (camd_init_undistort_rectify_map; bit-identical to the host properties above)."""
         key = str(device)
         if key not in self._dev:
-            to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-            self._dev[key] = dict(
-                map1x=to(self.undistort_rectify_map1[0]), map1y=to(self.undistort_rectify_map1[1]),
-                map2x=to(self.undistort_rectify_map2[0]), map2y=to(self.undistort_rectify_map2[1]),
-                mask=to(self.rectify_valid_mask1.view(np.uint8)))
+            m1x, m1y, mask = imgproc.init_undistort_rectify_map(
+                self.cam1.K, self.cam1.D, self.R1, self.K, self.xy, valid_for=self.cam1.xy, device=device)
+            m2x, m2y = imgproc.init_undistort_rectify_map(
+                self.cam2.K, self.cam2.D, self.R2, self.K, self.xy, device=device)
+            self._dev[key] = dict(map1x=m1x, map1y=m1y, map2x=m2x, map2y=m2y, mask=mask)
         return self._dev[key]
 
     def table_bundle(self):
@@ -249,15 +264,11 @@ class Stereo:
         return depth
 
     def _unrectify_tables(self, device):
-        maps = getattr(self, "_unrectify_depth_maps", None)
-        if maps is None:
-            # utils.py:183-191: initUndistortRectifyMap(K, None, R1.T, cam1.K, cam1.xy), memoised
-            maps = geometry.init_undistort_rectify_map(self.K, None, self.R1.T, self.cam1.K, self.cam1.xy)
-            self._unrectify_depth_maps = maps
+        # utils.py:183-191: initUndistortRectifyMap(K, None, R1.T, cam1.K, cam1.xy), memoised per device
         key = "unrect:" + str(device)
         if key not in self._dev:
-            import torch
-            self._dev[key] = tuple(torch.from_numpy(m).to(device) for m in maps)
+            self._dev[key] = imgproc.init_undistort_rectify_map(self.K, None, self.R1.T, self.cam1.K, self.cam1.xy,
+                                                                device=device)
         return self._dev[key]
 
     def unrectify_depth(self, depth):
@@ -271,10 +282,7 @@ class Stereo:
         i1, was_np = self._to_dev(img1)
         key = "undist:" + str(i1.device)
         if key not in self._dev:
-            import torch
-            mxy, ma = imgproc.undistort_maps(self.cam1.K, self.cam1.D, self.cam1.xy)
-            self._dev[key] = (torch.from_numpy(mxy).to(i1.device),
-                              torch.from_numpy(ma.view(np.int16)).to(i1.device))
+            self._dev[key] = imgproc.undistort_maps_device(self.cam1.K, self.cam1.D, self.cam1.xy, device=i1.device)
         mxy, ma = self._dev[key]
         out = imgproc.remap_fixed_bilinear(i1, mxy, ma)
         return out.cpu().numpy() if was_np else out

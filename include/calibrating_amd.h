@@ -120,6 +120,20 @@ int camd_remap_fixed_bilinear_u8(const uint8_t* src, int sw, int sh, int cn, siz
 /* host, init time: the stripe-wise fixed-point maps of cv2.undistort (2*w*h int16 + w*h uint16) */
 int camd_undistort_maps_host(const double K[9], const double* dist, int ndist, int w, int h,
                              int16_t* mapxy_host, uint16_t* mapa_host);
+/* ---- rig tables on the GPU (init time, or per batch when the rig / target size changes) -------------
+ * replaces cv2.initUndistortRectifyMap(A, dist, R, Anew, (w, h), CV_32FC1):
+ *   stereo_camera.py:159-165 (rectify maps of both cameras)   utils.py:184-191 (unrectify maps)
+ * and, when valid_mask != NULL, valid_mask_from_remap (stereo_camera.py:167-176) against a src_w x src_h
+ * source image, fused.  A, Anew: 3x3 row-major host doubles; R: 3x3 or NULL (identity); dist: up to 12
+ * coefficients (k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4), host.  mapx / mapy: device float [h][w];
+ * valid_mask: device u8 [h][w] or NULL.  Bit-identical to the host construction (float64 internally,
+ * X/Y/W accumulated along each row like OpenCV's scalar loop).                                         */
+int camd_init_undistort_rectify_map(const double A[9], const double* dist, int ndist, const double* R,
+                                    const double Anew[9], int w, int h, float* mapx, float* mapy,
+                                    uint8_t* valid_mask, int src_w, int src_h, void* stream);
+/* device version of camd_undistort_maps_host: mapxy int16 [h][w][2], mapa uint16 [h][w] (device) */
+int camd_undistort_maps(const double K[9], const double* dist, int ndist, int w, int h, int16_t* mapxy,
+                        uint16_t* mapa, void* stream);
 /* host, init time: the 32x32-phase int16 weight tables cv2.remap uses (1024*64 / 1024*4 entries) */
 int camd_lanczos4_table_host(int16_t* tab_host);
 int camd_bilinear_table_host(int16_t* tab_host);

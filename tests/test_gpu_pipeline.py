@@ -210,3 +210,40 @@ def test_get_depth_batch_matches_per_pair():
             assert np.array_equal(got[k][i], ref[k], equal_nan=True), (i, k)
     with pytest.raises(ValueError):
         stereo.get_depth_batch(I1[0], I2[0])
+
+
+def test_tables_built_on_gpu_are_bit_identical(oracle):
+    """n2: camd_init_undistort_rectify_map / camd_undistort_maps against the oracle and the host construction."""
+    from calibrating_amd import geometry
+    rng = np.random.default_rng(5)
+    for (w, h), dist in (((320, 240), [-0.21, 0.07, 1e-3, -2e-3, 0.01]),
+                         ((1300, 70), [0.1, -0.05, 5e-4, 3e-4, 0.002, 0.03, -0.01, 0.004, 1e-3, -2e-3, 5e-4, 1e-4]),
+                         ((97, 33), None)):
+        K = np.array([[0.9 * w, 0, w / 2 + 3.3], [0, 0.95 * w, h / 2 - 1.7], [0, 0, 1]])
+        Kn = np.array([[0.8 * w, 0, w / 2], [0, 0.8 * w, h / 2], [0, 0, 1]])
+        R = geometry.rodrigues(rng.normal(0, 0.03, 3))
+        mx, my, mask = imgproc.init_undistort_rectify_map(K, dist, R, Kn, (w, h), valid_for=(w, h))
+        ox, oy = oracle.init_undistort_rectify_map(K, dist, R, Kn, (w, h))
+        assert np.array_equal(mx.cpu().numpy(), ox) and np.array_equal(my.cpu().numpy(), oy)
+        gx, gy = geometry.init_undistort_rectify_map(K, dist, R, Kn, (w, h))
+        assert np.array_equal(mx.cpu().numpy(), gx) and np.array_equal(my.cpu().numpy(), gy)
+        ref_mask = (-0.5 < ox) & (ox < w - 0.5) & (-0.5 < oy) & (oy < h - 0.5)
+        assert np.array_equal(mask.cpu().numpy().astype(bool), ref_mask)
+        # R = None (identity) and the fixed-point maps of cv2.undistort
+        mx, my = imgproc.init_undistort_rectify_map(K, dist, None, K, (w, h))
+        ox, oy = oracle.init_undistort_rectify_map(K, dist, None, K, (w, h))
+        assert np.array_equal(mx.cpu().numpy(), ox) and np.array_equal(my.cpu().numpy(), oy)
+        hxy, ha = imgproc.undistort_maps(K, dist, (w, h))
+        dxy, da = imgproc.undistort_maps_device(K, dist, (w, h))
+        assert np.array_equal(dxy.cpu().numpy(), hxy) and np.array_equal(da.cpu().numpy().view(np.uint16), ha)
+
+
+def test_stereo_device_tables_match_host_properties():
+    W, H = 320, 240
+    stereo = ca.Stereo.load(synthetic.rig(W, H))
+    tb = stereo._tables(torch.device("cuda", 0))
+    assert np.array_equal(tb["map1x"].cpu().numpy(), stereo.undistort_rectify_map1[0])
+    assert np.array_equal(tb["map1y"].cpu().numpy(), stereo.undistort_rectify_map1[1])
+    assert np.array_equal(tb["map2x"].cpu().numpy(), stereo.undistort_rectify_map2[0])
+    assert np.array_equal(tb["map2y"].cpu().numpy(), stereo.undistort_rectify_map2[1])
+    assert np.array_equal(tb["mask"].cpu().numpy().astype(bool), stereo.rectify_valid_mask1)
