@@ -67,6 +67,15 @@ SIGNATURES = {
     "camd_init_undistort_rectify_map": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "camd_undistort_maps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "camd_point_cloud_grid": (c_int, [c_int, c_int, c_double, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "camd_point_cloud_workspace_bytes": (c_size_t, [c_int, c_int, c_double]),
+    "camd_depth_to_point_cloud": (c_int, [c_void_p, c_int, c_int, c_void_p, c_double, c_void_p, c_void_p, c_size_t,
+                                          c_void_p, c_void_p, c_void_p]),
+    "camd_apply_T_to_point_cloud": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "camd_point_cloud_to_depth": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_int, c_int, c_double, c_void_p,
+                                          c_void_p, c_void_p]),
+    "camd_project_depth": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p]),
     "camd_lanczos4_table_host": (c_int, [c_void_p]),
     "camd_bilinear_table_host": (c_int, [c_void_p]),
     "camd_resize_linear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

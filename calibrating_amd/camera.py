@@ -76,3 +76,13 @@ class Cam(dict):
             with open(path, "w") as f:
                 f.write(yamlstr)
         return yamlstr
+
+    def project_cam2_depth(cam1, cam2, depth2, T=None, interpolation=1.5):
+        """Depth image of ``cam2`` re-projected into this camera (camera.py:298-309), on the GPU.
+        ``T`` = pose of cam2 in this camera (4x4); the reference's fallback that derives it from calibration
+        board detections (``get_T_cam2_in_self``) is outside the MI355X path, so ``T`` is required."""
+        if T is None:
+            raise NotImplementedError("pass T (cam2 in cam1): board-based extrinsics are outside the MI355X path")
+        from . import pointcloud
+        rate = pointcloud.get_appropriate_interpolation_rate(cam1, cam2, interpolation)
+        return pointcloud.project_depth(depth2, cam2.K, T, cam1.K, cam1.xy, interpolation_rate=rate)

@@ -161,6 +161,31 @@ int camd_unrectify_depth(const double* depth, int w, int h, const double M_row2_
                          const float* mapx, const float* mapy, double* out, int ow, int oh,
                          int batch, void* stream);
 
+/* ---- depth post-ops (the step after get_depth in the reference's demos) ---------------------------
+ * replaces utils.depth_to_point_cloud (utils.py:213-246): non-zero depths in row-major order of the sampling
+ * grid (the depth image itself, or its cv2.resize(INTER_NEAREST) to round(size * rate) when rate != 1) ->
+ * points [N][3] = Kinv * (u z, v z, z); uv (optional) [N][2] = the (u, v) of each point (return_xyzuv).
+ * depth: f64 [h][w]; capacity = rows available in points/uv (grid_w * grid_h always suffices, see
+ * camd_point_cloud_grid); *count (device u64) receives N; workspace: camd_point_cloud_workspace_bytes.   */
+int camd_point_cloud_grid(int w, int h, double rate, int* grid_w, int* grid_h);
+size_t camd_point_cloud_workspace_bytes(int w, int h, double rate);
+int camd_depth_to_point_cloud(const double* depth, int w, int h, const double Kinv_host[9], double rate,
+                              double* points, double* uv, size_t capacity, unsigned long long* count,
+                              void* workspace, void* stream);
+/* replaces utils.apply_T_to_point_cloud (utils.py:152-161): out = (T * [p, 1])[:3], T 4x4 row-major host */
+int camd_apply_T_to_point_cloud(const double* points, size_t n, const double T_host[16], double* out,
+                                void* stream);
+/* replaces utils.point_cloud_to_depth / point_cloud_to_arr2d without values (utils.py:249-318): project with
+ * K, round half-to-even to a pixel, nearest z wins (the reference sorts far-to-near and overwrites).
+ * points: f64 rows of point_stride >= 3 doubles; keys_ws: device scratch of w*h*8 bytes; depth: f64 [h][w] */
+int camd_point_cloud_to_depth(const double* points, size_t n, int point_stride, const double K_host[9], int w,
+                              int h, double bg_value, double* depth, unsigned long long* keys_ws, void* stream);
+/* replaces Cam.project_cam2_depth (camera.py:298-309) = the three calls above composed, as ONE scatter
+ * pass without materialising the point cloud: depth2 f64 [h2][w2] of camera 2 -> depth1 f64 [h1][w1].      */
+int camd_project_depth(const double* depth2, int w2, int h2, const double K2inv_host[9],
+                       const double T_2in1_host[16], const double K1_host[9], double rate, int w1, int h1,
+                       double* depth1, unsigned long long* keys_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

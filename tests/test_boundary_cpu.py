@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols():
     src = open(os.path.join(ROOT, "include", "calibrating_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(camd_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(camd_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_header_symbol():

@@ -241,3 +241,21 @@ def test_oracle_refuses_undefined_narrow_case(oracle):
     with pytest.raises(ValueError):
         oracle.sgbm_compute(img, img, numDisparities=64, blockSize=5)
     assert oracle.sgbm_compute(img, img, numDisparities=64, blockSize=3).shape == (12, 66)
+
+
+def test_pointcloud_oracle_roundtrip_and_zbuffer():
+    """oracle/pointcloud_ref.py: depth -> cloud -> depth is the identity; the nearest point wins a pixel."""
+    from oracle import pointcloud_ref as ref
+    K = np.array([[200.0, 0, 31.5], [0, 200.0, 23.5], [0, 0, 1]])
+    rng = np.random.default_rng(0)
+    depth = 1 + rng.random((48, 64))
+    depth[rng.random((48, 64)) < 0.3] = 0
+    cloud = ref.depth_to_point_cloud(depth, K)
+    assert cloud.shape == ((depth != 0).sum(), 3)
+    assert np.allclose(ref.point_cloud_to_depth(cloud, K, (64, 48)), depth)
+    two = np.array([[0.0, 0.0, 3.0], [0.0, 0.0, 2.0], [0.0, 0.0, 5.0]])
+    assert ref.point_cloud_to_depth(two, K, (64, 48))[24, 32] == 2.0
+    up = ref.depth_to_point_cloud(depth, K, interpolation_rate=2, return_xyzuv=True)
+    assert up.shape[1] == 5 and up[:, 3].max() <= 63.5
+    assert ref.resize_nearest(np.arange(6.0).reshape(2, 3), (6, 4)).tolist() == [
+        [0, 0, 1, 1, 2, 2], [0, 0, 1, 1, 2, 2], [3, 3, 4, 4, 5, 5], [3, 3, 4, 4, 5, 5]]
