@@ -24,6 +24,8 @@ CAMD_ERR_NOMEM = -5
 
 MODE_SGBM = 0
 MODE_HH = 1
+MODE_SGBM_3WAY = 2  # not implemented (cv2's tiled variant)
+MODE_HH4 = 3
 INTER_NEAREST = 0
 INTER_LINEAR = 1
 INTER_LANCZOS4 = 4

@@ -560,8 +560,9 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
         return CAMD_ERR_BAD_ARG;
     }
     if (p->numDisparities <= 0) { set_error("numDisparities must be > 0"); return CAMD_ERR_BAD_ARG; }
-    if (p->mode != CAMD_MODE_SGBM && p->mode != CAMD_MODE_HH) {
-        set_error("mode %d not implemented (MODE_SGBM=0, MODE_HH=1)", p->mode);
+    if (p->mode != CAMD_MODE_SGBM && p->mode != CAMD_MODE_HH && p->mode != CAMD_MODE_HH4) {
+        set_error("mode %d not implemented (MODE_SGBM=0, MODE_HH=1, MODE_HH4=3; MODE_SGBM_3WAY is a tiled variant "
+                  "without a thread-count independent answer)", p->mode);
         return CAMD_ERR_UNSUPPORTED;
     }
     memset(g, 0, sizeof(*g));
@@ -580,7 +581,7 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
     g->SW2 = bs / 2;
     g->ftzero = (p->preFilterCap > 15 ? p->preFilterCap : 15) | 1;
     g->mode = p->mode;
-    g->npaths = p->mode == CAMD_MODE_HH ? 8 : 5;
+    g->npaths = p->mode == CAMD_MODE_HH ? 8 : (p->mode == CAMD_MODE_HH4 ? 4 : 5);
     g->speckleWindowSize = p->speckleWindowSize;
     g->speckleRange = p->speckleRange;
     if (2 * g->SW2 + 1 > HSUM_RING) {
@@ -671,7 +672,7 @@ static int launch_wta(const camd_sgbm* h, const uint16_t* S, int nvol, size_t di
 
 // one band-wavefront pass over `batch` pairs (sgbm_band.hpp): full = H, V, Dg, A of sweep (sx, sy);
 // !full = the row-parallel H-only pass
-static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int batch, hipStream_t st)
+static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int batch, hipStream_t st, bool diag = true)
 {
     const Geom& g = h->g;
     BandArgs a;
@@ -685,20 +686,22 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     CAMD_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
     dim3 grid(h->nbands * batch), block(BAND_BLOCK);
     const bool pad = g.Dp != g.D;
-#define CAMD_BAND(LN, NVV, FF, MM)                                                               \
-    do {                                                                                          \
-        if (pad) hipLaunchKernelGGL((k_band<LN, NVV, FF, MM, true>), grid, block, 0, st, a, g);  \
-        else hipLaunchKernelGGL((k_band<LN, NVV, FF, MM, false>), grid, block, 0, st, a, g);     \
+#define CAMD_BAND(LN, NVV, FF, MM, DG)                                                                 \
+    do {                                                                                               \
+        if (pad) hipLaunchKernelGGL((k_band<LN, NVV, FF, MM, true, DG>), grid, block, 0, st, a, g);    \
+        else hipLaunchKernelGGL((k_band<LN, NVV, FF, MM, false, DG>), grid, block, 0, st, a, g);       \
     } while (0)
-#define CAMD_BAND_SHAPE(FF, MM)                                   \
-    do {                                                           \
-        if (g.lanes == 16 && g.nv == 1) CAMD_BAND(16, 1, FF, MM); \
-        else if (g.lanes == 16) CAMD_BAND(16, 2, FF, MM);         \
-        else CAMD_BAND(8, 1, FF, MM);                             \
+#define CAMD_BAND_SHAPE(FF, MM, DG)                                    \
+    do {                                                               \
+        if (g.lanes == 16 && g.nv == 1) CAMD_BAND(16, 1, FF, MM, DG);  \
+        else if (g.lanes == 16) CAMD_BAND(16, 2, FF, MM, DG);          \
+        else CAMD_BAND(8, 1, FF, MM, DG);                              \
     } while (0)
-    if (full && mode == 0) CAMD_BAND_SHAPE(true, 0);
-    else if (full && mode == 2) CAMD_BAND_SHAPE(true, 2);
-    else if (!full && mode == 2) CAMD_BAND_SHAPE(false, 2);
+    if (full && mode == 0 && diag) CAMD_BAND_SHAPE(true, 0, true);
+    else if (full && mode == 2 && diag) CAMD_BAND_SHAPE(true, 2, true);
+    else if (full && mode == 0) CAMD_BAND_SHAPE(true, 0, false);
+    else if (full && mode == 2) CAMD_BAND_SHAPE(true, 2, false);
+    else if (!full && mode == 2) CAMD_BAND_SHAPE(false, 2, true);
     else { set_error("band pass (full %d, mode %d) not instantiated", (int)full, mode); return CAMD_ERR_UNSUPPORTED; }
 #undef CAMD_BAND_SHAPE
 #undef CAMD_BAND
@@ -941,13 +944,20 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
                            (g.minD - 1) * 16);
         CAMD_LAUNCH_CHECK();
         int rc;
-        rc = launch_band(h, +1, +1, true, 0, batch, st);                                  // ->  v  \.  ./
-        if (rc == CAMD_OK)
-            rc = g.mode == CAMD_MODE_HH ? launch_band(h, -1, -1, true, 2, batch, st)      // <-  ^  \^  /^ + WTA
-                                        : launch_band(h, -1, +1, false, 2, batch, st);    // <- + WTA
+        if (g.mode == CAMD_MODE_HH4) {
+            rc = launch_band(h, +1, +1, true, 0, batch, st, false);                            // ->  v
+            if (rc == CAMD_OK) rc = launch_band(h, -1, -1, true, 2, batch, st, false);         // <-  ^ + WTA
+        } else {
+            rc = launch_band(h, +1, +1, true, 0, batch, st);                                   // ->  v  \.  ./
+            if (rc == CAMD_OK)
+                rc = g.mode == CAMD_MODE_HH ? launch_band(h, -1, -1, true, 2, batch, st)       // <-  ^  \^  /^ + WTA
+                                            : launch_band(h, -1, +1, false, 2, batch, st);     // <- + WTA
+        }
         if (rc != CAMD_OK) return rc;
     } else {
-        static const int dirs[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1}};
+        static const int dirs8[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1}};
+        static const int dirs4[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
+        const int (*dirs)[2] = g.mode == CAMD_MODE_HH4 ? dirs4 : dirs8;
         if (multi) {
             int rc = launch_scan<true>(h, dirs, g.npaths, h->Smulti, dir_stride, batch, st);
             if (rc != CAMD_OK) return rc;

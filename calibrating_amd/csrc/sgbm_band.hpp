@@ -154,7 +154,8 @@ __device__ __forceinline__ void band_wta(const uint32_t (&s)[4 * NV], const uint
 
 // FULL: H, V, Dg, A of sweep (sx, sy), skew 2.  !FULL: H of sweep sx only (rows independent).
 // MODE: 0 = first pass (S written), 2 = final (S read, WTA; S stored only for the parity hook)
-template <int LANES, int NV, bool FULL, int MODE, bool PAD>
+// DIAG = false (MODE_HH4): the two diagonal directions are left out (their slots travel as zeros)
+template <int LANES, int NV, bool FULL, int MODE, bool PAD, bool DIAG = true>
 __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a, Geom g)
 {
     constexpr int NR = 4 * NV;
@@ -419,12 +420,14 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
                     dVo = sgm_step<LANES, NR, PAD>(Vin, dV, cc, LVo, keep, sent, P1pk, P2pk, li);
 #pragma unroll
                     for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LVo[k]);
-                    dDo = sgm_step<LANES, NR, PAD>(Din, dD, cc, LDo, keep, sent, P1pk, P2pk, li);
+                    if (DIAG) {
+                        dDo = sgm_step<LANES, NR, PAD>(Din, dD, cc, LDo, keep, sent, P1pk, P2pk, li);
 #pragma unroll
-                    for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LDo[k]);
-                    dAo = sgm_step<LANES, NR, PAD>(An, dAn, cc, LAo, keep, sent, P1pk, P2pk, li);
+                        for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LDo[k]);
+                        dAo = sgm_step<LANES, NR, PAD>(An, dAn, cc, LAo, keep, sent, P1pk, P2pk, li);
 #pragma unroll
-                    for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LAo[k]);
+                        for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LAo[k]);
+                    }
                 }
                 if (MODE != 2 || a.write_S) {
                     uint4* sp = reinterpret_cast<uint4*>(Srow + cell_off(xi));

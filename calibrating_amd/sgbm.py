@@ -14,8 +14,11 @@ from . import _native
 
 MODE_SGBM = _native.MODE_SGBM
 MODE_HH = _native.MODE_HH
+MODE_HH4 = _native.MODE_HH4
+MODE_SGBM_3WAY = _native.MODE_SGBM_3WAY
 STEREO_SGBM_MODE_SGBM = MODE_SGBM
 STEREO_SGBM_MODE_HH = MODE_HH
+STEREO_SGBM_MODE_HH4 = MODE_HH4
 DISP_SHIFT = 4
 DISP_SCALE = 16
 

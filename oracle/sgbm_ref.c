@@ -1,5 +1,5 @@
 /*
- * sgbm_ref.c -- scalar CPU restatement of cv::StereoSGBM::compute (modes MODE_SGBM and MODE_HH).
+ * sgbm_ref.c -- scalar CPU restatement of cv::StereoSGBM::compute (modes MODE_SGBM, MODE_HH, MODE_HH4).
  *
  * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED: OpenCV is a third-party dependency
  * of the reference (`opencv-contrib-python>=4.7.0.72`, /root/reference/requirements.txt:2) that is
@@ -458,6 +458,166 @@ static int compute_disparity_sgbm(const PixType* img1, const PixType* img2, int 
 #undef GET_MINLR
 }
 
+/* ---- stereosgbm.cpp: computeDisparitySGBM_HH4 (MODE_HH4 = 3) -----------------------------------
+ * Four paths: a vertical stage (CalcVerticalSums: every column top-down then bottom-up, S = L_down, then
+ * S += L_up) and a horizontal stage (CalcHorizontalSums: every row left-to-right, then right-to-left with
+ * the winner-take-all / uniqueness / disp2 / sub-pixel tail in the same loop, then the left-right check).
+ * C(x,y,d) is the same box-filtered BT cost (+P2) as in computeDisparitySGBM, taken from it by capture. */
+static void lr_update(const CostType* Cp, const CostType* Lprev /* guards at [-1], [D] */, int minprev,
+                      CostType* Lout, int* minout, int D, int P1, int P2)
+{
+    int delta = minprev + P2, mn = MAX_COST;
+    for (int d = 0; d < D; d++) {
+        int L = Cp[d] + imin((int)Lprev[d], imin(Lprev[d - 1] + P1, imin(Lprev[d + 1] + P1, delta))) - delta;
+        Lout[d] = (CostType)L;
+        mn = imin(mn, L);
+    }
+    *minout = mn;
+}
+
+static int compute_disparity_hh4(const PixType* img1, const PixType* img2, int width, int height, int cn,
+                                 size_t step, DispType* disp1, const oracle_sgbm_params* params,
+                                 const capture* cap)
+{
+    int minD = params->minDisparity, maxD = minD + params->numDisparities;
+    int uniquenessRatio = params->uniquenessRatio >= 0 ? params->uniquenessRatio : 10;
+    int disp12MaxDiff = params->disp12MaxDiff > 0 ? params->disp12MaxDiff : 1;
+    int P1 = params->P1 > 0 ? params->P1 : 2;
+    int P2 = imax(params->P2 > 0 ? params->P2 : 5, P1 + 1);
+    int minX1 = imax(maxD, 0), maxX1 = width + imin(minD, 0);
+    const int D = params->numDisparities;
+    int width1 = maxX1 - minX1;
+    int INVALID_DISP = minD - 1, INVALID_DISP_SCALED = INVALID_DISP * DISP_SCALE;
+    int SADWindowSize = params->blockSize > 0 ? params->blockSize : 5;
+    if (minX1 >= maxX1) {
+        for (size_t i = 0; i < (size_t)width * height; i++) disp1[i] = (DispType)INVALID_DISP_SCALED;
+        return 0;
+    }
+    if (width1 <= SADWindowSize / 2) return -2;
+
+    size_t costWidth = (size_t)width1 * D, vol = costWidth * height;
+    CostType* C = (CostType*)malloc(vol * sizeof(CostType));
+    CostType* S = (CostType*)calloc(vol, sizeof(CostType));
+    CostType* Lbuf = (CostType*)malloc((size_t)(D + 2) * 2 * sizeof(CostType));
+    CostType* disp2cost = (CostType*)malloc((size_t)width * sizeof(CostType));
+    DispType* disp2ptr = (DispType*)malloc((size_t)width * sizeof(DispType));
+    DispType* scratch = (DispType*)malloc((size_t)width * height * sizeof(DispType));
+    if (!C || !S || !Lbuf || !disp2cost || !disp2ptr || !scratch) {
+        free(C); free(S); free(Lbuf); free(disp2cost); free(disp2ptr); free(scratch);
+        return -1;
+    }
+    {   /* the cost volume of the row-incremental code path (mode 0 computes the same C) */
+        oracle_sgbm_params q = *params;
+        q.mode = 0;
+        capture ccap = {C, NULL};
+        int rc = compute_disparity_sgbm(img1, img2, width, height, cn, step, scratch, &q, &ccap);
+        if (rc) { free(C); free(S); free(Lbuf); free(disp2cost); free(disp2ptr); free(scratch); return rc; }
+    }
+    if (cap && cap->C) memcpy(cap->C, C, vol * sizeof(CostType));
+    CostType* La = Lbuf + 1;
+    CostType* Lb = Lbuf + (D + 2) + 1;
+
+    /* vertical stage */
+    for (int x = 0; x < width1; x++) {
+        for (int dir = 0; dir < 2; dir++) {
+            CostType *prev = La, *cur = Lb;
+            int minprev = 0;
+            memset(prev, 0, (size_t)D * sizeof(CostType));
+            for (int k = 0; k < height; k++) {
+                int y = dir == 0 ? k : height - 1 - k;
+                prev[-1] = prev[D] = MAX_COST;
+                int mn;
+                lr_update(C + (size_t)y * costWidth + (size_t)x * D, prev, minprev, cur, &mn, D, P1, P2);
+                CostType* Sp = S + (size_t)y * costWidth + (size_t)x * D;
+                for (int d = 0; d < D; d++) Sp[d] = sat16(Sp[d] + cur[d]);
+                minprev = mn;
+                CostType* t = prev; prev = cur; cur = t;
+            }
+        }
+    }
+
+    /* horizontal stage */
+    for (int y = 0; y < height; y++) {
+        DispType* disp1ptr = disp1 + (size_t)y * width;
+        const CostType* Crow = C + (size_t)y * costWidth;
+        CostType* Srow = S + (size_t)y * costWidth;
+        int x, d;
+        {   /* left to right */
+            CostType *prev = La, *cur = Lb;
+            int minprev = 0;
+            memset(prev, 0, (size_t)D * sizeof(CostType));
+            for (x = 0; x < width1; x++) {
+                prev[-1] = prev[D] = MAX_COST;
+                int mn;
+                lr_update(Crow + (size_t)x * D, prev, minprev, cur, &mn, D, P1, P2);
+                CostType* Sp = Srow + (size_t)x * D;
+                for (d = 0; d < D; d++) Sp[d] = sat16(Sp[d] + cur[d]);
+                minprev = mn;
+                CostType* t = prev; prev = cur; cur = t;
+            }
+        }
+        for (x = 0; x < width; x++) {
+            disp1ptr[x] = disp2ptr[x] = (DispType)INVALID_DISP_SCALED;
+            disp2cost[x] = MAX_COST;
+        }
+        {   /* right to left + winner-take-all */
+            CostType *prev = La, *cur = Lb;
+            int minprev = 0;
+            memset(prev, 0, (size_t)D * sizeof(CostType));
+            for (x = width1 - 1; x >= 0; x--) {
+                prev[-1] = prev[D] = MAX_COST;
+                int mn;
+                lr_update(Crow + (size_t)x * D, prev, minprev, cur, &mn, D, P1, P2);
+                CostType* Sp = Srow + (size_t)x * D;
+                int minS = MAX_COST, bestDisp = -1;
+                for (d = 0; d < D; d++) {
+                    int Sval = Sp[d] = sat16(Sp[d] + cur[d]);
+                    if (Sval < minS) { minS = Sval; bestDisp = d; }
+                }
+                minprev = mn;
+                { CostType* t = prev; prev = cur; cur = t; }
+
+                for (d = 0; d < D; d++)
+                    if (Sp[d] * (100 - uniquenessRatio) < minS * 100 && abs(bestDisp - d) > 1) break;
+                if (d < D) continue;
+                d = bestDisp;
+                int _x2 = x + minX1 - d - minD;
+                if (disp2cost[_x2] > minS) {
+                    disp2cost[_x2] = (CostType)minS;
+                    disp2ptr[_x2] = (DispType)(d + minD);
+                }
+                if (0 < d && d < D - 1) {
+                    int denom2 = imax(Sp[d - 1] + Sp[d + 1] - 2 * Sp[d], 1);
+                    d = d * DISP_SCALE + ((Sp[d - 1] - Sp[d + 1]) * DISP_SCALE + denom2) / (denom2 * 2);
+                } else
+                    d *= DISP_SCALE;
+                disp1ptr[x + minX1] = (DispType)(d + minD * DISP_SCALE);
+            }
+        }
+        for (x = minX1; x < maxX1; x++) {
+            int d1 = disp1ptr[x];
+            if (d1 == INVALID_DISP_SCALED) continue;
+            int _d = d1 >> DISP_SHIFT;
+            int d_ = (d1 + DISP_SCALE - 1) >> DISP_SHIFT;
+            int _x = x - _d, x_ = x - d_;
+            if (0 <= _x && _x < width && disp2ptr[_x] >= minD && abs(disp2ptr[_x] - _d) > disp12MaxDiff &&
+                0 <= x_ && x_ < width && disp2ptr[x_] >= minD && abs(disp2ptr[x_] - d_) > disp12MaxDiff)
+                disp1ptr[x] = (DispType)INVALID_DISP_SCALED;
+        }
+    }
+    if (cap && cap->S) memcpy(cap->S, S, vol * sizeof(CostType));
+    free(C); free(S); free(Lbuf); free(disp2cost); free(disp2ptr); free(scratch);
+    return 0;
+}
+
+/* mode dispatch: 0 / 1 -> computeDisparitySGBM, 3 -> computeDisparitySGBM_HH4 */
+static int compute_disparity(const PixType* img1, const PixType* img2, int width, int height, int cn, size_t step,
+                             DispType* disp1, const oracle_sgbm_params* params, const capture* cap)
+{
+    if (params->mode == 3) return compute_disparity_hh4(img1, img2, width, height, cn, step, disp1, params, cap);
+    return compute_disparity_sgbm(img1, img2, width, height, cn, step, disp1, params, cap);
+}
+
 /* ---- median_blur.simd.hpp: medianBlur_SortNet, m == 3, int16, replicate border ------------- */
 static inline void mm_op(int* a, int* b)
 {
@@ -569,7 +729,7 @@ static int check_args(const oracle_sgbm_params* p, int width, int height, int cn
 {
     if (!p || width <= 0 || height <= 0 || (cn != 1 && cn != 3)) return -1;
     if (p->numDisparities <= 0) return -1;
-    if (p->mode != 0 && p->mode != 1) return -1;
+    if (p->mode != 0 && p->mode != 1 && p->mode != 3) return -1; /* MODE_SGBM_3WAY (2): result depends on cv2's thread count */
     return 0;
 }
 
@@ -577,7 +737,7 @@ int oracle_sgbm_raw(const oracle_sgbm_params* p, const uint8_t* left, const uint
                     int width, int height, int cn, size_t step, int16_t* disp)
 {
     if (check_args(p, width, height, cn)) return -1;
-    return compute_disparity_sgbm(left, right, width, height, cn, step, disp, p, NULL);
+    return compute_disparity(left, right, width, height, cn, step, disp, p, NULL);
 }
 
 int oracle_sgbm_compute(const oracle_sgbm_params* p, const uint8_t* left, const uint8_t* right,
@@ -587,7 +747,7 @@ int oracle_sgbm_compute(const oracle_sgbm_params* p, const uint8_t* left, const 
     size_t n = (size_t)width * height;
     int16_t* tmp = (int16_t*)malloc(n * sizeof(int16_t));
     if (!tmp) return -1;
-    int rc = compute_disparity_sgbm(left, right, width, height, cn, step, tmp, p, NULL);
+    int rc = compute_disparity(left, right, width, height, cn, step, tmp, p, NULL);
     if (rc == 0) {
         /* medianBlur(disp, disp, 3): in place = out of place on a copy */
         oracle_median3_s16(tmp, disp, width, height);
@@ -625,7 +785,7 @@ int oracle_sgbm_cost_volume(const oracle_sgbm_params* p, const uint8_t* left, co
     int16_t* tmp = (int16_t*)malloc((size_t)width * height * sizeof(int16_t));
     if (!tmp) return -1;
     capture cap = {C, NULL};
-    int rc = compute_disparity_sgbm(left, right, width, height, cn, step, tmp, p, &cap);
+    int rc = compute_disparity(left, right, width, height, cn, step, tmp, p, &cap);
     free(tmp);
     return rc;
 }
@@ -637,7 +797,7 @@ int oracle_sgbm_aggregated(const oracle_sgbm_params* p, const uint8_t* left, con
     int16_t* tmp = (int16_t*)malloc((size_t)width * height * sizeof(int16_t));
     if (!tmp) return -1;
     capture cap = {NULL, S};
-    int rc = compute_disparity_sgbm(left, right, width, height, cn, step, tmp, p, &cap);
+    int rc = compute_disparity(left, right, width, height, cn, step, tmp, p, &cap);
     free(tmp);
     return rc;
 }

@@ -135,10 +135,11 @@ def aggregate_dir(C, P1, P2, dx, dy):
 
 DIRS_SGBM = [(1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0)]
 DIRS_HH = DIRS_SGBM + [(1, -1), (0, -1), (-1, -1)]
+DIRS_HH4 = [(1, 0), (0, 1), (-1, 0), (0, -1)]
 
 
 def aggregate(C, q):
-    dirs = DIRS_HH if q["mode"] == 1 else DIRS_SGBM
+    dirs = {0: DIRS_SGBM, 1: DIRS_HH, 3: DIRS_HH4}[q["mode"]]
     S = np.zeros(C.shape, np.int64)
     for dx, dy in dirs:
         S += aggregate_dir(C, q["P1"], q["P2"], dx, dy)

@@ -65,6 +65,10 @@ CASES = [
     (30, 120, 48, 1, 7, -7, 1),    # negative minDisparity, padded D
     (25, 140, 100, 1, 9, 3, 0),    # D not a multiple of 8
     (20, 64, 40, 3, 5, 5, 1),
+    (48, 200, 128, 3, 5, 0, 3),    # MODE_HH4 (4 paths), two bands
+    (61, 150, 64, 1, 3, 1, 3),     # MODE_HH4, 8-lane groups
+    (30, 330, 256, 1, 5, 0, 3),    # MODE_HH4, 2 vectors per lane
+    (25, 97, 24, 1, 5, 0, 3),      # MODE_HH4 on the scan paths only (D <= 32)
 ]
 
 

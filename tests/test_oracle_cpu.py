@@ -22,6 +22,7 @@ def _p(cn, D, bs, minD=0, mode=0, **kw):
 @pytest.mark.parametrize("H,W,D,cn,minD,bs,mode", [
     (24, 64, 16, 1, 0, 3, 0), (20, 70, 16, 3, 0, 5, 0), (18, 60, 16, 1, 2, 5, 1),
     (20, 72, 24, 3, -3, 3, 1), (16, 50, 10, 1, 0, 7, 0), (12, 90, 40, 1, 4, 11, 1),
+    (22, 66, 16, 1, 0, 5, 3), (17, 75, 24, 3, 2, 3, 3),   # MODE_HH4
 ])
 def test_oracle_matches_numpy_model_stagewise(oracle, H, W, D, cn, minD, bs, mode):
     left, right = synthetic.rectified_pair(seed=5, H=H, W=W, D=max(D, 8), cn=cn)
@@ -44,7 +45,7 @@ def test_oracle_matches_numpy_model_noise_and_speckle(oracle):
         assert np.array_equal(oracle.sgbm_compute(left, right, **p), M.sgbm_compute(left, right, **p))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 3])
 def test_known_answer_constant_shift(oracle, mode):
     rng = np.random.default_rng(0)
     H, W, D, d0 = 40, 160, 32, 11
