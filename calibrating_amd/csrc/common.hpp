@@ -67,6 +67,13 @@ __device__ __forceinline__ uint32_t pk_addsat_i16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2_t, a),
                                                                       __builtin_bit_cast(s16x2_t, b)));
 }
+// a * b + c per half, saturated to 0xFFFF (v_pk_mad_u16 ... clamp)
+__device__ __forceinline__ uint32_t pk_mad_sat_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t pk_lshr_u16(uint32_t a, uint32_t sh_pk)
 {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, a) >> __builtin_bit_cast(u16x2_t, sh_pk));

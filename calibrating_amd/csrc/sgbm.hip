@@ -41,6 +41,7 @@ struct Geom {
     int ftzero;
     int lanes, nv;         // line-group shape: Dp = lanes*8*nv
     int mode, npaths;
+    uint32_t uniq_magic;   // floor(2^32 / (100 - uniq)) + 1, or 0 when 100 - uniq == 1 (band WTA)
     int speckleWindowSize, speckleRange;
 };
 
@@ -95,9 +96,15 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
     };
     const uint8_t* imgR = right + (size_t)pair * image_stride;
     const uint8_t* imgL = left + (size_t)pair * image_stride;
+#ifdef CAMD_DBG_HSUM_NOSTAGE
+    if (g.W == -1)
+#endif
     for (int e = threadIdx.x; e < ncols + 2; e += blockDim.x)
 #pragma unroll
         for (int c = 0; c < CN; c++) stage[e * ES + c * 3] = plane(imgR, colbase - 1 + e, c);
+#ifdef CAMD_DBG_HSUM_NOSTAGE
+    if (g.W == -1)
+#endif
     for (int e = threadIdx.x; e < nleft + 2; e += blockDim.x)
 #pragma unroll
         for (int c = 0; c < CN; c++) lstage[e * ES + c * 3] = plane(imgL, clo + g.minX1 - 1 + e, c);
@@ -113,7 +120,13 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
             dst[e * ES + c * 3 + 2] = pk_max_u16(pk_max_u16(ul, ur), u);
         }
     };
+#ifdef CAMD_DBG_HSUM_NOSTAGE
+    if (g.W == -1)
+#endif
     for (int i = threadIdx.x; i < ncols; i += blockDim.x) finish(stage, i + 1, colbase + i);
+#ifdef CAMD_DBG_HSUM_NOSTAGE
+    if (g.W == -1)
+#endif
     for (int i = threadIdx.x; i < nleft; i += blockDim.x) finish(lstage, i + 1, clo + g.minX1 + i);
     __syncthreads();
     const uint4* lent = reinterpret_cast<const uint4*>(lstage) + (ES / 4);  // skip the halo entry
@@ -127,7 +140,11 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
     struct Ops { uint32_t V[CN], V0[CN], V1[CN], U[CN], U0[CN], U1[CN]; };
     auto fetch = [&](int t, Ops& o) {
         const int ct = min(max(t, 0), g.W1 - 1);  // clamped virtual column (box sum replicates the border)
+#ifdef CAMD_DBG_HSUM_NORIGHT
+        const uint4* e = ent;
+#else
         const uint4* e = ent + (size_t)(ct - clo) * (ES / 4);
+#endif
         if (CN == 1) {
             uint4 a = e[0];
             o.V[0] = a.x; o.V0[0] = a.y; o.V1[0] = a.z;
@@ -153,7 +170,11 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
     const int t0 = xs - g.SW2, t1 = xe - 1 + g.SW2;
     auto step = [&](int t, const Ops& o, Ops& nxt) {
         fetch(min(t + 1, t1), nxt);
+#ifdef CAMD_DBG_HSUM_NORING
+        uint32_t old = 0;
+#else
         uint32_t old = ring[slot * 64 + lane];
+#endif
         uint32_t acc = 0;
 #pragma unroll
         for (int c = 0; c < CN; c++) {
@@ -166,11 +187,18 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, m),
                                          __builtin_bit_cast(u16x2_t, 0x00010001u), acc, false);
         }
+#ifndef CAMD_DBG_HSUM_NORING
         ring[slot * 64 + lane] = acc;
+#endif
         slot = slot + 1 == K ? 0 : slot + 1;
         run += acc - old;
         int xo = t - g.SW2;
+#ifdef CAMD_DBG_HSUM_NOSTORE  // measurement variants (never part of the product build)
+        asm volatile("" ::"v"(run));
+        if (xo == -12345) {
+#else
         if (xo >= xs) {
+#endif
             uint16_t* o16 = out + (size_t)xo * g.Dp;
             if (wr_valid) *o16 = (uint16_t)run;
             else if (wr_pad) *o16 = 0;
@@ -573,6 +601,7 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
     int maxX1 = width + (g->minD < 0 ? g->minD : 0);
     g->W1 = maxX1 - g->minX1;
     g->uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
+    g->uniq_magic = (g->uniq <= 98) ? (uint32_t)((1ull << 32) / (unsigned)(100 - g->uniq) + 1) : 0u;
     g->d12 = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
     g->P1 = p->P1 > 0 ? p->P1 : 2;
     int P2 = p->P2 > 0 ? p->P2 : 5;

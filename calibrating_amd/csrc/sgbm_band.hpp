@@ -93,9 +93,10 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&Lp)[NR], uint32_t 
 // u64 words of one (pair, band) edge block: per column LANES x 6NV vector words, then 2 words of deltas
 static inline size_t band_erec_stride(int W1, int lanes, int nv) { return (size_t)W1 * ((size_t)lanes * 6 * nv + 2); }
 
-// winner-take-all on the final S of one pixel (bit-exact with k_wta): called by all lanes of the group
+// winner-take-all on the final S of one pixel (bit-exact with k_wta): called by all lanes of the group.
+// dpk[k] = the two disparities of register k, packed (d | d+1 << 16).
 template <int LANES, int NV>
-__device__ __forceinline__ void band_wta(const uint32_t (&s)[4 * NV], const uint32_t (&dlo)[4 * NV], uint4* wS,
+__device__ __forceinline__ void band_wta(const uint32_t (&s)[4 * NV], const uint32_t (&dpk)[4 * NV], uint4* wS,
                                          const BandArgs& a, const Geom& g, int pair, int y, int x, int grp, int li)
 {
     constexpr int NR = 4 * NV;
@@ -103,8 +104,8 @@ __device__ __forceinline__ void band_wta(const uint32_t (&s)[4 * NV], const uint
     uint32_t key = 0xffffffffu;
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-        key = min(key, (s[k] << 16) | dlo[k]);
-        key = min(key, (s[k] & 0xffff0000u) | (dlo[k] + 1u));
+        key = min(key, __builtin_amdgcn_perm(s[k], dpk[k], 0x05040100u));  // S.lo << 16 | d
+        key = min(key, __builtin_amdgcn_perm(s[k], dpk[k], 0x07060302u));  // S.hi << 16 | d + 1
     }
     key = group_min_u32_full<LANES>(key);
     const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
@@ -113,16 +114,21 @@ __device__ __forceinline__ void band_wta(const uint32_t (&s)[4 * NV], const uint
     for (int v = 0; v < NV; v++)
         wS[threadIdx.x * NV + v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
     // (2) uniqueness: S[d]*(100-u) < minS*100 for some |d-best| > 1
-    //     <=>  min over those d of S[d]  <=  T = floor((minS*100 - 1) / (100-u))
+    //     <=>  min over those d of S[d]  <=  T = floor((minS*100 - 1) / (100-u)); the division by the launch
+    //     constant 100-u is a multiply-high by floor(2^32/(100-u)) + 1, exact for numerators < 2^32/100
     int T = -1;
-    if (minS > 0) T = (int)__fdiv_rn((float)(minS * 100 - 1), (float)(100 - g.uniq));
-    const int t0 = (int)dlo[0] - (best - 1);  // element offset of this lane from best-1
-    uint32_t far = SENT_PK | 0x80008000u;      // 0xFFFF in both halves
+    if (minS > 0) {
+        const uint32_t n = (uint32_t)(minS * 100 - 1);
+        T = (int)(g.uniq_magic ? __umulhi(n, g.uniq_magic) : n);
+    }
+    // the window best-1 .. best+1 is masked out in packed arithmetic: diff = d - (best-1) (mod 2^16) is 0, 1, 2
+    // exactly there, w = sat(3 - diff) is non-zero exactly there, and sat(w * 0xFFFF + S) = 0xFFFF
+    const uint32_t bm1 = dup16((uint32_t)(best - 1));
+    uint32_t far = 0xffffffffu;
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-        const int tk = t0 + 2 * k;
-        uint32_t ex = ((unsigned)tk < 3u ? 0xffffu : 0u) | ((unsigned)(tk + 1) < 3u ? 0xffff0000u : 0u);
-        far = pk_min_u16(far, s[k] | ex);
+        const uint32_t w = pk_subsat_u16(0x00030003u, pk_sub_u16(dpk[k], bm1));
+        far = pk_min_u16(far, pk_mad_sat_u16(w, 0xffffffffu, s[k]));
     }
     const int minfar = (int)(group_min_dup16<LANES>(far) & 0xffffu);
     if (li == 0 && minS < MAX_COST && minfar > T) {
@@ -196,11 +202,11 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
     const bool producer = !helper && has_next && grp == glast;
 
     const uint32_t P1pk = dup16((uint32_t)g.P1), P2pk = dup16((uint32_t)g.P2);
-    uint32_t keep[NR], sent[NR], dlo[NR];
+    uint32_t keep[NR], sent[NR], dpk[NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         int d0 = li * 8 * NV + 2 * k;
-        dlo[k] = (uint32_t)d0;
+        dpk[k] = (uint32_t)d0 | ((uint32_t)(d0 + 1) << 16);
         uint32_t kp = (d0 < g.D ? 0xffffu : 0u) | (d0 + 1 < g.D ? 0xffff0000u : 0u);
         keep[k] = kp;
         sent[k] = ~kp & SENT_PK;
@@ -434,7 +440,11 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
 #pragma unroll
                     for (int v = 0; v < NV; v++) sp[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
                 }
-                if (MODE == 2) band_wta<LANES, NV>(s, dlo, wS, a, g, pair, y, a.sx > 0 ? xi : W1 - 1 - xi, grp, li);
+#ifdef CAMD_DBG_BAND_NOWTA  // measurement variant (never part of the product build)
+                if (MODE == 2) asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]));
+#else
+                if (MODE == 2) band_wta<LANES, NV>(s, dpk, wS, a, g, pair, y, a.sx > 0 ? xi : W1 - 1 - xi, grp, li);
+#endif
             }
             if (FULL) {
                 const int wb = u & 1;
