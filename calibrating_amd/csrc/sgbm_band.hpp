@@ -93,11 +93,18 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&Lp)[NR], uint32_t 
 // u64 words of one (pair, band) edge block: per column LANES x 6NV vector words, then 2 words of deltas
 static inline size_t band_erec_stride(int W1, int lanes, int nv) { return (size_t)W1 * ((size_t)lanes * 6 * nv + 2); }
 
-// winner-take-all on the final S of one pixel (bit-exact with k_wta): called by all lanes of the group.
+// Winner-take-all on the final S of one pixel (bit-exact with k_wta), in two parts.
+//   band_wta_step   every step, all lanes of the group: minS / best by a min-reduce over keys, the uniqueness
+//                   test, and the two sub-pixel neighbours; the outcome is CAPTURED into lane (t mod LANES)
+//   band_wta_flush  every LANES steps: each lane finishes the pixel it captured (right-view atomicMin,
+//                   parabola, store) -- the scalar tail runs with all 64 lanes busy instead of one per group
 // dpk[k] = the two disparities of register k, packed (d | d+1 << 16).
+static constexpr uint32_t WTA_NONE = 0xffffffffu;
+
 template <int LANES, int NV>
-__device__ __forceinline__ void band_wta(const uint32_t (&s)[4 * NV], const uint32_t (&dpk)[4 * NV], uint4* wS,
-                                         const BandArgs& a, const Geom& g, int pair, int y, int x, int grp, int li)
+__device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const uint32_t (&dpk)[4 * NV], uint4* wS,
+                                              const Geom& g, int grp, int li, int t, bool act, uint32_t& cap_key,
+                                              uint32_t& cap_nb)
 {
     constexpr int NR = 4 * NV;
     // (1) minS and the smallest d attaining it: min over keys (S << 16 | d); padded d >= D hold 0x7FFF
@@ -109,7 +116,7 @@ __device__ __forceinline__ void band_wta(const uint32_t (&s)[4 * NV], const uint
     }
     key = group_min_u32_full<LANES>(key);
     const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
-    // park S so that lane 0 can pick S[best-1], S[best+1] without a select tree
+    // park S so that S[best-1], S[best+1] can be picked without a select tree
 #pragma unroll
     for (int v = 0; v < NV; v++)
         wS[threadIdx.x * NV + v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
@@ -131,14 +138,29 @@ __device__ __forceinline__ void band_wta(const uint32_t (&s)[4 * NV], const uint
         far = pk_min_u16(far, pk_mad_sat_u16(w, 0xffffffffu, s[k]));
     }
     const int minfar = (int)(group_min_dup16<LANES>(far) & 0xffffu);
-    if (li == 0 && minS < MAX_COST && minfar > T) {
-        int d = best;
+    const bool ok = act && minS < MAX_COST && minfar > T;
+    // (3) neighbours for the sub-pixel parabola (same address in every lane of the group: an LDS broadcast)
+    const uint16_t* gs = reinterpret_cast<const uint16_t*>(wS) + (size_t)grp * (LANES * 8 * NV);
+    const uint32_t Sm = gs[max(best - 1, 0)], Sp = gs[min(best + 1, LANES * 8 * NV - 1)];
+    if (li == (t & (LANES - 1))) {
+        cap_key = ok ? key : WTA_NONE;
+        cap_nb = Sm | (Sp << 16);
+    }
+}
+
+// x: column (cost coordinates) of the pixel this lane captured
+template <int LANES, int NV>
+__device__ __forceinline__ void band_wta_flush(const BandArgs& a, const Geom& g, int pair, int y, int x,
+                                               uint32_t& cap_key, uint32_t cap_nb)
+{
+    if (cap_key != WTA_NONE) {
+        const int minS = (int)(cap_key >> 16);
+        int d = (int)(cap_key & 0xffffu);
         const int x2 = x + g.minX1 - d - g.minD;
         const size_t ro = ((size_t)pair * g.H + y) * (size_t)g.W;
         atomicMin(a.keys + ro + x2, ((uint32_t)minS << 16) | (uint32_t)(0xffff - d));
         if (0 < d && d < g.D - 1) {
-            const uint16_t* gs = reinterpret_cast<const uint16_t*>(wS) + (size_t)grp * (LANES * 8 * NV);
-            const int Sm = gs[d - 1], Sp = gs[d + 1];
+            const int Sm = (int)(cap_nb & 0xffffu), Sp = (int)(cap_nb >> 16);
             const int denom2 = max(Sm + Sp - 2 * minS, 1);
             const int num = (Sm - Sp) * 16 + denom2, den = denom2 * 2;
             // num / den truncated toward zero; |quotient| <= 8: reciprocal estimate + fix-up
@@ -156,6 +178,7 @@ __device__ __forceinline__ void band_wta(const uint32_t (&s)[4 * NV], const uint
             d *= 16;
         a.d1[ro + x + g.minX1] = (int16_t)(d + g.minD * 16);
     }
+    cap_key = WTA_NONE;
 }
 
 // FULL: H, V, Dg, A of sweep (sx, sy), skew 2.  !FULL: H of sweep sx only (rows independent).
@@ -347,6 +370,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
     }
 
     const int nsteps = (W1 + SK * glast + RING - 1) / RING * RING;
+    uint32_t cap_key = WTA_NONE, cap_nb = 0;  // FINAL: the pixel this lane finishes at the next flush
     if (FULL && helper) {
         // The helper runs its own loop with the same number of barriers: keeping the two roles in separate
         // loops leaves the compute loop free of control flow around its loads, which is what lets the
@@ -443,8 +467,13 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
 #ifdef CAMD_DBG_BAND_NOWTA  // measurement variant (never part of the product build)
                 if (MODE == 2) asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]));
 #else
-                if (MODE == 2) band_wta<LANES, NV>(s, dpk, wS, a, g, pair, y, a.sx > 0 ? xi : W1 - 1 - xi, grp, li);
+                if (MODE == 2) band_wta_step<LANES, NV>(s, dpk, wS, g, grp, li, t, true, cap_key, cap_nb);
 #endif
+            }
+            if (MODE == 2 && ((t & (LANES - 1)) == LANES - 1 || t == nsteps - 1)) {
+                // lane li captured the pixel of step t - ((t mod LANES) - li)
+                const int xc = xi - ((t & (LANES - 1)) - li);
+                band_wta_flush<LANES, NV>(a, g, pair, y, a.sx > 0 ? xc : W1 - 1 - xc, cap_key, cap_nb);
             }
             if (FULL) {
                 const int wb = u & 1;
