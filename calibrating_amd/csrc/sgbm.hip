@@ -265,6 +265,47 @@ __global__ __launch_bounds__(256) void k_vsum(const uint4* __restrict__ Hs, uint
     }
 }
 
+// Register-ring variant for the common block sizes (K = 2*SH2+1 known at compile time): no LDS at all, so
+// its workgroups can share a CU with the LDS-hungry cost kernel of another stream.
+template <int K>
+__global__ __launch_bounds__(256) void k_vsum_reg(const uint4* __restrict__ Hs, uint4* __restrict__ C, Geom g,
+                                                  size_t vol_stride16)
+{
+    constexpr int SH2 = K / 2;
+    const size_t rowv = (size_t)g.W1 * (g.Dp / 8);
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i0 < rowv;
+    const size_t i = ok ? i0 : rowv - 1;
+    const int pair = blockIdx.z, H = g.H;
+    const int y0 = blockIdx.y * VSUM_ROWS, y1 = min(y0 + VSUM_ROWS, H);
+    const uint4* base = Hs + (size_t)pair * vol_stride16 + i;
+    uint4* out = C + (size_t)pair * vol_stride16 + i;
+    auto ld = [&](int yy) -> uint4 { return base[(size_t)min(max(yy, 0), H - 1) * rowv]; };
+    const uint32_t p2 = dup16((uint32_t)g.P2);
+    uint4 acc = make_uint4(p2, p2, p2, p2);
+    uint4 ring[K];  // slot j: row y0 - SH2 + j, later replaced in rotation (static indices: the loop steps by K)
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        ring[j] = ld(y0 - SH2 + j);
+        acc.x = pk_add_u16(acc.x, ring[j].x); acc.y = pk_add_u16(acc.y, ring[j].y);
+        acc.z = pk_add_u16(acc.z, ring[j].z); acc.w = pk_add_u16(acc.w, ring[j].w);
+    }
+    if (ok) out[(size_t)y0 * rowv] = acc;
+    for (int y = y0 + 1; y < y1; y += K) {
+        uint4 nv[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) nv[j] = ld(y + j + SH2);  // unconditional (clamped): issued back to back
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const uint4 v = nv[j], o = ring[j];
+            ring[j] = v;
+            acc.x = pk_sub_u16(pk_add_u16(acc.x, v.x), o.x); acc.y = pk_sub_u16(pk_add_u16(acc.y, v.y), o.y);
+            acc.z = pk_sub_u16(pk_add_u16(acc.z, v.z), o.z); acc.w = pk_sub_u16(pk_add_u16(acc.w, v.w), o.w);
+            if (ok && y + j < y1) out[(size_t)(y + j) * rowv] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_scan: L_r along direction r = (dx, dy) for every line of the cost array, accumulated into S.
 //   L(p,d) = C(p,d) + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, minLp+P2) - (minLp+P2),  Lp = L(p-r,.)
@@ -938,10 +979,17 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     MARK(ST_VSUM);
     {
         size_t rowv = (size_t)g.W1 * (g.Dp / 8);
-        hipLaunchKernelGGL(k_vsum, dim3(div_up((long long)rowv, 256), div_up(g.H, VSUM_ROWS), batch), dim3(256),
-                           (size_t)(2 * g.SW2 + 1) * 256 * sizeof(uint4), st,
-                           reinterpret_cast<const uint4*>(h->S), reinterpret_cast<uint4*>(h->C), g,
-                           h->vol_elems / 8);
+        const dim3 vgrid(div_up((long long)rowv, 256), div_up(g.H, VSUM_ROWS), batch);
+        const uint4* hs4 = reinterpret_cast<const uint4*>(h->S);
+        uint4* c4 = reinterpret_cast<uint4*>(h->C);
+        switch (2 * g.SW2 + 1) {
+#define CAMD_VSUM(KK) case KK: hipLaunchKernelGGL((k_vsum_reg<KK>), vgrid, dim3(256), 0, st, hs4, c4, g, h->vol_elems / 8); break
+            CAMD_VSUM(1); CAMD_VSUM(3); CAMD_VSUM(5); CAMD_VSUM(7); CAMD_VSUM(9); CAMD_VSUM(11);
+#undef CAMD_VSUM
+            default:
+                hipLaunchKernelGGL(k_vsum, vgrid, dim3(256), (size_t)(2 * g.SW2 + 1) * 256 * sizeof(uint4), st, hs4, c4,
+                                   g, h->vol_elems / 8);
+        }
         CAMD_LAUNCH_CHECK();
     }
 
