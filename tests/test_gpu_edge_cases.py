@@ -107,3 +107,30 @@ def test_sgbm_pitched_and_batched_inputs(oracle):
     assert all(np.array_equal(got9[i], ref) for i in range(9))
     got1 = m.compute(left, right)                                # back to one pair on the same handle
     assert np.array_equal(got1, ref)
+
+
+def test_sgbm_randomised_shapes_and_parameters(oracle):
+    """Seeded fuzz: random sizes, channel counts, disparity ranges, block sizes, penalties and modes; every
+    aggregation path against the oracle, bit-exact."""
+    rng = np.random.default_rng(20240929)
+    for case in range(24):
+        cn = int(rng.choice([1, 3]))
+        D = int(rng.choice([16, 32, 48, 64, 96, 128, 160, 256]))
+        bs = int(rng.choice([1, 3, 5, 7, 9]))
+        minD = int(rng.integers(-6, 7))
+        W = D + abs(minD) + int(rng.integers(bs // 2 + 2, 90))
+        H = int(rng.integers(3, 70))
+        mode = int(rng.choice([0, 1, 3]))
+        P1 = int(rng.integers(1, 8 * cn * bs * bs + 2))
+        P2 = P1 + int(rng.integers(1, 32 * cn * bs * bs + 2))
+        p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=P1, P2=min(P2, 15000), disp12MaxDiff=int(rng.integers(-1, 4)),
+                 uniquenessRatio=int(rng.integers(0, 30)), preFilterCap=int(rng.choice([0, 15, 31, 63])),
+                 speckleWindowSize=int(rng.choice([0, 0, 40])), speckleRange=int(rng.integers(1, 4)), mode=mode)
+        if case % 3 == 0:
+            left, right = _rand_pair(case, H, W, cn)
+        else:
+            left, right = synthetic.rectified_pair(seed=case, H=H, W=W, D=max(min(D, W // 2), 8), cn=cn)
+        try:
+            _check(oracle, left, right, p)
+        except AssertionError as e:
+            raise AssertionError("case %d %s %s: %s" % (case, (H, W, cn), p, e))
