@@ -76,21 +76,25 @@ __device__ void uf_union(int* parent, int a, int b)
     }
 }
 
-__global__ __launch_bounds__(256) void k_cc_init(int* parent, int* count, int n)
+// all kernels: blockIdx.z = image of the batch; parent / count hold 2*n ints per image (labels are local)
+__global__ __launch_bounds__(256) void k_cc_init(int* parent, int n)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
+    int* par = parent + (size_t)blockIdx.z * 2 * n;
     if (i < n) {
-        parent[i] = i;
-        count[i] = 0;
+        par[i] = i;
+        par[n + i] = 0;
     }
 }
 
-__global__ __launch_bounds__(256) void k_cc_merge(const int16_t* __restrict__ img, size_t pitch, int* parent,
-                                                  int w, int h, int new_val, int max_diff)
+__global__ __launch_bounds__(256) void k_cc_merge(const int16_t* __restrict__ img, size_t pitch, size_t stride,
+                                                  int* parent, int w, int h, int new_val, int max_diff)
 {
     int x = blockIdx.x * 256 + threadIdx.x;
     int y = blockIdx.y;
     if (x >= w) return;
+    img += (size_t)blockIdx.z * stride;
+    parent += (size_t)blockIdx.z * 2 * w * h;
     int v = img[(size_t)y * pitch + x];
     if (v == new_val) return;
     int i = y * w + x;
@@ -104,12 +108,15 @@ __global__ __launch_bounds__(256) void k_cc_merge(const int16_t* __restrict__ im
     }
 }
 
-__global__ __launch_bounds__(256) void k_cc_count(const int16_t* __restrict__ img, size_t pitch, int* parent,
-                                                  int* count, int w, int h, int new_val)
+__global__ __launch_bounds__(256) void k_cc_count(const int16_t* __restrict__ img, size_t pitch, size_t stride,
+                                                  int* parent, int w, int h, int new_val)
 {
     int x = blockIdx.x * 256 + threadIdx.x;
     int y = blockIdx.y;
     if (x >= w) return;
+    img += (size_t)blockIdx.z * stride;
+    parent += (size_t)blockIdx.z * 2 * w * h;
+    int* count = parent + w * h;
     if (img[(size_t)y * pitch + x] == new_val) return;
     int i = y * w + x;
     int r = uf_find(parent, i);
@@ -117,13 +124,16 @@ __global__ __launch_bounds__(256) void k_cc_count(const int16_t* __restrict__ im
     atomicAdd(&count[r], 1);
 }
 
-__global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, const int* __restrict__ parent,
-                                                  const int* __restrict__ count, int w, int h, int new_val,
+__global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, size_t stride,
+                                                  const int* __restrict__ parent, int w, int h, int new_val,
                                                   int max_size)
 {
     int x = blockIdx.x * 256 + threadIdx.x;
     int y = blockIdx.y;
     if (x >= w) return;
+    img += (size_t)blockIdx.z * stride;
+    parent += (size_t)blockIdx.z * 2 * w * h;
+    const int* count = parent + w * h;
     int16_t* p = img + (size_t)y * pitch + x;
     if (*p == new_val) return;
     // the forest is final here, but path halving in k_cc_count may have left parent[i] pointing at an
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, co
 size_t speckle_ws_bytes(int w, int h, int batch)
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
-    return (size_t)w * h * 2 * sizeof(int);  // parent + count, reused pair after pair
+    return (size_t)batch * w * h * 2 * sizeof(int);  // parent + count per image: the whole batch in one launch
 }
 
 int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, int new_val, int max_size,
@@ -145,17 +155,12 @@ int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, 
     if (!ws) { set_error("speckle workspace is NULL"); return CAMD_ERR_BAD_ARG; }
     int n = w * h;
     int* parent = reinterpret_cast<int*>(ws);
-    int* count = parent + n;
-    dim3 grid(div_up(w, 256), h);
-    for (int b = 0; b < batch; b++) {
-        int16_t* im = img + (size_t)b * stride_e;
-        hipLaunchKernelGGL(k_cc_init, dim3(div_up(n, 256)), dim3(256), 0, st, parent, count, n);
-        hipLaunchKernelGGL(k_cc_merge, grid, dim3(256), 0, st, im, pitch_e, parent, w, h, new_val, max_diff);
-        hipLaunchKernelGGL(k_cc_count, grid, dim3(256), 0, st, im, pitch_e, parent, count, w, h, new_val);
-        hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), 0, st, im, pitch_e, parent, count, w, h, new_val,
-                           max_size);
-        CAMD_LAUNCH_CHECK();
-    }
+    dim3 grid(div_up(w, 256), h, batch);
+    hipLaunchKernelGGL(k_cc_init, dim3(div_up(n, 256), 1, batch), dim3(256), 0, st, parent, n);
+    hipLaunchKernelGGL(k_cc_merge, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
+    hipLaunchKernelGGL(k_cc_count, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val);
+    hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_size);
+    CAMD_LAUNCH_CHECK();
     return CAMD_OK;
 }
 
