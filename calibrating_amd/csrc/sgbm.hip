@@ -132,7 +132,8 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
     const uint4* lent = reinterpret_cast<const uint4*>(lstage) + (ES / 4);  // skip the halo entry
 
     uint16_t* __restrict__ out = Hs + (size_t)pair * vol_stride + ((size_t)y * g.W1) * g.Dp + d;
-    const bool wr_valid = d < g.D, wr_pad = d < g.Dp;
+    if (d >= g.Dp) return;  // lanes beyond the padded range only helped with the staging (no barrier follows)
+    const uint32_t vmask = d < g.D ? 0xffffu : 0u;  // padded disparities D <= d < Dp are written as 0
     const uint4* ent = reinterpret_cast<const uint4*>(stage) + (size_t)(last - d + 1) * (ES / 4);
 
     // Software pipeline: the operands of step t+1 (three ds_read_b128 + the scalar loads of the left
@@ -199,9 +200,7 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
 #else
         if (xo >= xs) {
 #endif
-            uint16_t* o16 = out + (size_t)xo * g.Dp;
-            if (wr_valid) *o16 = (uint16_t)run;
-            else if (wr_pad) *o16 = 0;
+            out[(size_t)xo * g.Dp] = (uint16_t)(run & vmask);  // one unconditional store: no exec juggling
         }
     };
     Ops A, B;
