@@ -9,4 +9,6 @@ for l in sys.stdin:
 timeout 900 python -m pytest tests/test_gpu_sgbm.py tests/test_gpu_edge_cases.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
 ENVV=(A=1)
 run --mode sgbm --batch 64
-run --mode hh --batch 64
+run --mode sgbm --batch 64 --channels 1
+run --mode sgbm --batch 64 --block 11
+
