@@ -30,7 +30,7 @@ namespace camd {
 
 static constexpr uint32_t SENT_PK = 0x7fff7fffu;  // MAX_COST in both halves
 static constexpr int MAX_COST = 32767;
-static constexpr int CAMD_MULTI_MAX_BATCH = 4;  // concurrent-direction path keeps npaths volumes per pair
+static constexpr int CAMD_MULTI_MAX_BATCH = 8;  // concurrent-direction path: npaths volumes for up to 8 pairs per call
 
 struct Geom {
     int W, H, cn;          // image
@@ -1031,23 +1031,29 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     // aggregation path: fused band passes win on throughput (>= ~8 pairs per launch), concurrent
     // per-direction scans on latency (a few pairs: every direction gets its own S volume and all of them
     // run at once), sequential scans are the generic fallback
+    // Measured at 1080p / D=128 (tools/gpu_batch_sweep.py, ms per pair): the concurrent scans win up to 4 pairs
+    // per call for 5 paths (3.1 / 2.4 / 2.0 against 6.8 / 3.7 / 2.2 through the band passes) and up to 8 pairs
+    // for 8 paths (3.6 ... 2.6 against 13.1 ... 2.9); from there on the band passes take over (1.36 / 1.87 at 16
+    // pairs, 0.98 / 1.14 at 64).
+    const int mcap = h->max_batch < CAMD_MULTI_MAX_BATCH ? h->max_batch : CAMD_MULTI_MAX_BATCH;
     int path = h->path;
     if (path == CAMD_PATH_AUTO) {
-        if (batch < 8 && h->max_batch <= CAMD_MULTI_MAX_BATCH) path = CAMD_PATH_CONCURRENT;
-        else if (h->band_ok) path = CAMD_PATH_BAND;
-        else path = CAMD_PATH_SCAN;
+        // the thresholds scale with the work per pair (in units of one 1080p / D=128 volume)
+        const double work = (double)batch * ((double)g.H * g.W1 * g.Dp) / (1080.0 * 1792.0 * 128.0);
+        if (work <= (g.mode == CAMD_MODE_HH ? 8.0 : 4.0) || !h->band_ok) path = CAMD_PATH_CONCURRENT;
+        else path = CAMD_PATH_BAND;
     }
     if (path == CAMD_PATH_BAND && !h->band_ok) path = CAMD_PATH_SCAN;
     if (path == CAMD_PATH_CONCURRENT) {
-        if (h->max_batch > CAMD_MULTI_MAX_BATCH) path = CAMD_PATH_SCAN;
+        if (batch > mcap) path = h->band_ok && h->path == CAMD_PATH_AUTO ? CAMD_PATH_BAND : CAMD_PATH_SCAN;
         else if (!h->Smulti) {
-            hipError_t e = hipMalloc((void**)&h->Smulti, (size_t)g.npaths * h->max_batch * h->vol_elems * 2);
-            if (e != hipSuccess) { (void)hipGetLastError(); path = CAMD_PATH_SCAN; }
+            hipError_t e = hipMalloc((void**)&h->Smulti, (size_t)g.npaths * mcap * h->vol_elems * 2);
+            if (e != hipSuccess) { (void)hipGetLastError(); path = h->band_ok ? CAMD_PATH_BAND : CAMD_PATH_SCAN; }
         }
     }
     const bool band = path == CAMD_PATH_BAND;
     const bool multi = path == CAMD_PATH_CONCURRENT;
-    const size_t dir_stride = (size_t)h->max_batch * h->vol_elems;
+    const size_t dir_stride = (size_t)mcap * h->vol_elems;
     MARK(ST_SCAN);
     if (band) {
         // fused passes: every pass reads C once and touches S once for up to four directions

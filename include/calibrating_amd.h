@@ -77,10 +77,11 @@ int camd_sgbm_query(const camd_sgbm* h, int* width1, int* D, int* Dp, int* minX1
  * 2 = raw disparity before median/speckle as int16 [height][width] */
 int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* stream);
 /* options: CAMD_OPT_PATH selects the aggregation implementation (all bit-identical):
- *   CAMD_PATH_AUTO (default)  concurrent scans for < 8 pairs per call on small handles, else band passes
+ *   CAMD_PATH_AUTO (default)  concurrent scans for calls of <= 4 pairs of 1080p/D=128-sized work (<= 8 for
+ *                             MODE_HH), band passes above
  *   CAMD_PATH_SCAN            one line-scan launch per direction, sequential (generic fallback)
  *   CAMD_PATH_BAND            fused band-wavefront passes (throughput; D in (32, 256])
- *   CAMD_PATH_CONCURRENT      all directions at once into per-direction volumes (latency; max_batch <= 4)
+ *   CAMD_PATH_CONCURRENT      all directions at once into per-direction volumes (latency; <= 8 pairs per call)
  * CAMD_OPT_KEEP_S 1 = the band path also stores the final S volume (for camd_sgbm_debug_copy(which = 1)). */
 enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1 };
 enum { CAMD_PATH_AUTO = 0, CAMD_PATH_SCAN = 1, CAMD_PATH_BAND = 2, CAMD_PATH_CONCURRENT = 3 };
