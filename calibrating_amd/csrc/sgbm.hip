@@ -402,7 +402,6 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
     for (int k = 0; k < NR; k++) Lp[k] = 0;
     uint32_t delta = P2pk;  // minLp = 0
 
-    uint32_t c[NR], s[NR];
     auto load = [&](const uint4* p, uint32_t* dst) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
@@ -410,65 +409,72 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
             dst[4 * v] = q.x; dst[4 * v + 1] = q.y; dst[4 * v + 2] = q.z; dst[4 * v + 3] = q.w;
         }
     };
-    load(cp, c);
-    if (!FIRST) load(sp, s);
+    // A line is a dependent chain (every pixel needs the previous one), so with one pair per call the kernel is
+    // latency-bound: the C (and S) vectors of the next PF-1 pixels are kept in flight in a register ring.  The
+    // loop is unrolled by PF so the ring never moves, and the loads are unconditional (clamped to the line's last
+    // pixel) so that the compiler can wait with counted vmcnt(N) instead of draining the ring every step.
+    constexpr int PF = NV == 1 ? 8 : (NV == 2 ? 4 : 2);
+    uint32_t cr[PF][NR], sr[FIRST ? 1 : PF][NR];
+#pragma unroll
+    for (int u = 0; u < PF - 1; u++) {
+        const ptrdiff_t o = (ptrdiff_t)min(u, len - 1) * step4;
+        load(cp + o, cr[u]);
+        if (!FIRST) load(sp + o, sr[u]);
+    }
+    for (int i0 = 0; i0 < len; i0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int i = i0 + u;
+            {
+                const ptrdiff_t o = (ptrdiff_t)min(i + PF - 1, len - 1) * step4;
+                load(cp + o, cr[(u + PF - 1) % PF]);
+                if (!FIRST) load(sp + o, sr[(u + PF - 1) % PF]);
+            }
+            if (i < len) {
+                const uint32_t(&c)[NR] = cr[u];
+                // neighbours across lanes: d-1 of my first element, d+1 of my last element
+                uint32_t prev_last = dpp_mov<DPP_ROW_SHR1>(SENT_PK, Lp[NR - 1]);
+                uint32_t next_first = dpp_mov<DPP_ROW_SHL1>(SENT_PK, Lp[0]);
+                if (LANES < 16) {
+                    if (li == 0) prev_last = SENT_PK;
+                    if (li == LANES - 1) next_first = SENT_PK;
+                }
+                // m[k] = (Lp[2k-1], Lp[2k]) ; m[k+1] = (Lp[2k+1], Lp[2k+2])
+                uint32_t m[NR + 1];
+                m[0] = alignbit16(Lp[0], prev_last);
+#pragma unroll
+                for (int k = 1; k < NR; k++) m[k] = alignbit16(Lp[k], Lp[k - 1]);
+                m[NR] = alignbit16(next_first, Lp[NR - 1]);
 
-    for (int i = 0; i < len; i++) {
-        // prefetch the next pixel of the line
-        uint32_t cn_[NR], sn_[NR];
-        const bool more = i + 1 < len;
-        if (more) {
-            load(cp + step4, cn_);
-            if (!FIRST) load(sp + step4, sn_);
-        }
-        // neighbours across lanes: d-1 of my first element, d+1 of my last element
-        uint32_t prev_last = dpp_mov<DPP_ROW_SHR1>(SENT_PK, Lp[NR - 1]);
-        uint32_t next_first = dpp_mov<DPP_ROW_SHL1>(SENT_PK, Lp[0]);
-        if (LANES < 16) {
-            if (li == 0) prev_last = SENT_PK;
-            if (li == LANES - 1) next_first = SENT_PK;
-        }
-        // m[k] = (Lp[2k-1], Lp[2k]) ; m[k+1] = (Lp[2k+1], Lp[2k+2])
-        uint32_t m[NR + 1];
-        m[0] = alignbit16(Lp[0], prev_last);
+                uint32_t L[NR];
+                uint32_t mn = SENT_PK;
 #pragma unroll
-        for (int k = 1; k < NR; k++) m[k] = alignbit16(Lp[k], Lp[k - 1]);
-        m[NR] = alignbit16(next_first, Lp[NR - 1]);
+                for (int k = 0; k < NR; k++) {
+                    uint32_t t = pk_add_u16(pk_min_u16(m[k], m[k + 1]), P1pk);
+                    uint32_t a = pk_min_u16(pk_min_u16(Lp[k], t), delta);
+                    uint32_t l = pk_sub_u16(pk_add_u16(c[k], a), delta);
+                    if (PAD) l = (l & keep[k]) | sent[k];
+                    L[k] = l;
+                    mn = pk_min_u16(mn, l);
+                }
+                mn = group_min_pk_u16<LANES>(mn);
+                mn = pk_min_u16(mn, alignbit16(mn, mn));  // both halves = min over all d
+                delta = pk_add_u16(mn, P2pk);
 
-        uint32_t L[NR];
-        uint32_t mn = SENT_PK;
+                uint32_t s[NR];
 #pragma unroll
-        for (int k = 0; k < NR; k++) {
-            uint32_t t = pk_add_u16(pk_min_u16(m[k], m[k + 1]), P1pk);
-            uint32_t a = pk_min_u16(pk_min_u16(Lp[k], t), delta);
-            uint32_t l = pk_sub_u16(pk_add_u16(c[k], a), delta);
-            if (PAD) l = (l & keep[k]) | sent[k];
-            L[k] = l;
-            mn = pk_min_u16(mn, l);
-        }
-        mn = group_min_pk_u16<LANES>(mn);
-        mn = pk_min_u16(mn, alignbit16(mn, mn));  // both halves = min over all d
-        delta = pk_add_u16(mn, P2pk);
-
+                for (int k = 0; k < NR; k++) {
+                    s[k] = FIRST ? L[k] : pk_addsat_i16(sr[FIRST ? 0 : u][k], L[k]);
+                    Lp[k] = L[k];
+                }
+                uint4* so = sp + (ptrdiff_t)i * step4;
 #pragma unroll
-        for (int k = 0; k < NR; k++) {
-            s[k] = FIRST ? L[k] : pk_addsat_i16(s[k], L[k]);
-            Lp[k] = L[k];
-        }
-#pragma unroll
-        for (int v = 0; v < NV; v++) sp[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
-
-        cp += step4;
-        sp += step4;
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < NR; k++) {
-                c[k] = cn_[k];
-                if (!FIRST) s[k] = sn_[k];
+                for (int v = 0; v < NV; v++) so[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
             }
         }
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // k_wta: one workgroup per image row.  Per cost column x (a LANES-lane group each):
