@@ -134,3 +134,37 @@ def test_sgbm_randomised_shapes_and_parameters(oracle):
             _check(oracle, left, right, p)
         except AssertionError as e:
             raise AssertionError("case %d %s %s: %s" % (case, (H, W, cn), p, e))
+
+
+def test_c_abi_pitched_buffers(oracle):
+    """camd_sgbm_compute with row pitches / pair strides larger than the packed sizes (straight through the ABI)."""
+    import ctypes
+    from calibrating_amd import _native
+    H, W, cn, D, nb = 37, 210, 3, 64, 3
+    p = dict(minDisparity=0, numDisparities=D, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1, uniquenessRatio=10,
+             speckleWindowSize=40, speckleRange=2)
+    pairs = [synthetic.rectified_pair(seed=30 + i, H=H, W=W, D=D, cn=cn) for i in range(nb)]
+    pitch, istride = W * cn + 29, (H + 2) * (W * cn + 29) + 64          # bytes
+    dpitch, dstride = W + 11, (H + 1) * (W + 11) + 8                      # int16 elements
+    L = torch.zeros(nb * istride, dtype=torch.uint8, device="cuda")
+    R = torch.zeros(nb * istride, dtype=torch.uint8, device="cuda")
+    for i, (l, r) in enumerate(pairs):
+        for buf, img in ((L, l), (R, r)):
+            view = buf[i * istride:i * istride + H * pitch].view(H, pitch)
+            view[:, :W * cn] = torch.from_numpy(img.reshape(H, W * cn)).cuda()
+    out = torch.full((nb * dstride,), -999, dtype=torch.int16, device="cuda")
+    for path in (2, 1, 3):
+        hd = ctypes.c_void_p()
+        prm = _native.SgbmParams(**dict(dict(preFilterCap=0, mode=0), **p))
+        lib = _native.lib()
+        _native.check(lib.camd_sgbm_create(ctypes.byref(prm), W, H, cn, nb, ctypes.byref(hd)))
+        _native.check(lib.camd_sgbm_set_option(hd, 0, path))
+        _native.check(lib.camd_sgbm_compute(hd, L.data_ptr(), R.data_ptr(), pitch, istride, out.data_ptr(), dpitch * 2,
+                                            dstride * 2, nb, _native.current_stream()))
+        _native.check(lib.camd_sgbm_status(hd, _native.current_stream()))
+        res = out.cpu().numpy()
+        for i, (l, r) in enumerate(pairs):
+            got = res[i * dstride:i * dstride + H * dpitch].reshape(H, dpitch)
+            assert np.array_equal(got[:, :W], oracle.sgbm_compute(l, r, **p)), (path, i)
+            assert (got[:, W:] == -999).all()                             # padding untouched
+        _native.check(lib.camd_sgbm_destroy(hd))
