@@ -618,8 +618,9 @@ size_t speckle_ws_bytes(int w, int h, int batch);
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-enum Stage { ST_PREP = 0, ST_HSUM, ST_VSUM, ST_SCAN, ST_WTA, ST_POST, ST_COUNT };
-static const char* kStageNames[ST_COUNT] = {"bt_prepare", "hsum", "vsum", "scan", "wta", "median_speckle"};
+enum Stage { ST_PREP = 0, ST_HSUM, ST_VSUM, ST_SCAN, ST_SCAN2, ST_WTA, ST_POST, ST_COUNT };
+// "scan" = the aggregation launches; on the band path the last pass is timed separately as "scan_last"
+static const char* kStageNames[ST_COUNT] = {"bt_prepare", "hsum", "vsum", "scan", "scan_last", "wta", "median_speckle"};
 
 }  // namespace camd
 
@@ -1067,16 +1068,12 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         hipLaunchKernelGGL(k_wta_init, dim3(div_up((long long)npix, 256)), dim3(256), 0, st, h->keys, h->d1, npix,
                            (g.minD - 1) * 16);
         CAMD_LAUNCH_CHECK();
-        int rc;
-        if (g.mode == CAMD_MODE_HH4) {
-            rc = launch_band(h, +1, +1, true, 0, batch, st, false);                            // ->  v
-            if (rc == CAMD_OK) rc = launch_band(h, -1, -1, true, 2, batch, st, false);         // <-  ^ + WTA
-        } else {
-            rc = launch_band(h, +1, +1, true, 0, batch, st);                                   // ->  v  \.  ./
-            if (rc == CAMD_OK)
-                rc = g.mode == CAMD_MODE_HH ? launch_band(h, -1, -1, true, 2, batch, st)       // <-  ^  \^  /^ + WTA
-                                            : launch_band(h, -1, +1, false, 2, batch, st);     // <- + WTA
-        }
+        int rc = launch_band(h, +1, +1, true, 0, batch, st, g.mode != CAMD_MODE_HH4);          // ->  v  [\.  ./]
+        if (rc != CAMD_OK) return rc;
+        MARK(ST_SCAN2);
+        if (g.mode == CAMD_MODE_HH4) rc = launch_band(h, -1, -1, true, 2, batch, st, false);    // <-  ^ + WTA
+        else if (g.mode == CAMD_MODE_HH) rc = launch_band(h, -1, -1, true, 2, batch, st);       // <-  ^  \^  /^ + WTA
+        else rc = launch_band(h, -1, +1, false, 2, batch, st);                                  // <- + WTA
         if (rc != CAMD_OK) return rc;
     } else {
         static const int dirs8[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1}};
@@ -1092,6 +1089,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
                 if (rc != CAMD_OK) return rc;
             }
         }
+        MARK(ST_SCAN2);  // (no separate last pass on the scan paths: zero-length stage)
     }
 
     MARK(ST_WTA);
