@@ -45,7 +45,7 @@ static constexpr uint32_t BAND_SPIN_LIMIT = 1u << 20;    // ~0.1 s of s_sleep po
 struct BandArgs {
     const uint16_t* C;
     uint16_t* S;
-    unsigned long long* E;  // [pair][band] edge blocks: [W1][LANES][6*NV] u64 vectors, then [W1][2] u64 deltas
+    unsigned long long* E;  // [pair][band] edge blocks: [W1][6*NV][LANES] u64 vector words, then [W1][2] u64 deltas
     uint32_t* flags;        // [pair][band][nchunks], value == epoch when the chunk is published
     uint32_t* ticket;       // zeroed before every launch
     uint32_t* err;          // set to 1 if a bounded spin timed out
@@ -287,9 +287,12 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
     auto fetch_batch = [&](int b) {
         const int col = b * CPB + hl / LANES;
         if (col < W1) {
-            const unsigned long long* p = Ein + ((size_t)col * LANES + (hl % LANES)) * EVEC;
+            // record layout [column][word k][lane]: word k of the 16 lanes is one contiguous 128-byte run, so the
+            // 8-byte write-through stores of a group (and these loads) fill whole 64-byte sectors
+            const unsigned long long* p = Ein + (size_t)col * (LANES * EVEC) + (hl % LANES);
 #pragma unroll
-            for (int k = 0; k < EVEC; k++) pend[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < EVEC; k++)
+                pend[k] = __hip_atomic_load(p + k * LANES, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long* q = Ein + edelta + (size_t)col * 2;
             pdl[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pdl[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -485,15 +488,15 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
                 }
                 if (li == 0) xdl[wb][grp] = make_uint4(dVo, dDo, dAo, 0u);
                 if (producer && act) {
-                    unsigned long long* p = Eout + ((size_t)xi * LANES + li) * EVEC;
+                    unsigned long long* p = Eout + (size_t)xi * (LANES * EVEC) + li;
 #pragma unroll
                     for (int k = 0; k < 2 * NV; k++) {
-                        __hip_atomic_store(p + k, (unsigned long long)LVo[2 * k] | ((unsigned long long)LVo[2 * k + 1] << 32),
+                        __hip_atomic_store(p + k * LANES, (unsigned long long)LVo[2 * k] | ((unsigned long long)LVo[2 * k + 1] << 32),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(p + 2 * NV + k,
+                        __hip_atomic_store(p + (2 * NV + k) * LANES,
                                            (unsigned long long)LDo[2 * k] | ((unsigned long long)LDo[2 * k + 1] << 32),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(p + 4 * NV + k,
+                        __hip_atomic_store(p + (4 * NV + k) * LANES,
                                            (unsigned long long)LAo[2 * k] | ((unsigned long long)LAo[2 * k + 1] << 32),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
