@@ -5,8 +5,14 @@ A step = one pass of the SGBM hot path (BT cost volume -> path aggregation -> WT
 LR check -> median) over one batch of synthetic rectified pairs that are already resident in HBM.
 Independent pairs shard across ranks with no data-path collective ("scaling": "weak": every rank
 processes its own batch of --batch pairs); the only RCCL traffic is the one-time broadcast of the rig's
-remap tables and the end-of-run timing reduction.  Launch: python bench.py [--gpus N --steps K
---warmup W]; for N > 1 through torch.distributed.run, one rank per GPU.
+remap tables and the end-of-run reduction of timings / checksums.
+
+    python bench.py [--gpus N --steps K --warmup W]
+
+With --gpus N > 1 and no RANK in the environment the script launches itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); it exits non-zero with
+a message when fewer than N GPUs are visible.  Under an external torchrun it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment.
 
 Default workload = BASELINE.json configs[1]/[2]: 1920x1080 RGB pairs (the reference feeds RGB), D=128,
 blockSize=5, cv2's default MODE_SGBM (5 paths: the mode the reference's cv2.StereoSGBM_create call
@@ -16,6 +22,8 @@ throughput is also reported in "also" on every default run.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,13 +33,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PMC_PROFILE = "profiles/r02_pmc_traffic%s.json"  # committed rocprofv3 --pmc summary the `traffic` fields come from
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (default: >= 3 s of GPU work)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -40,15 +49,17 @@ def parse():
     ap.add_argument("--channels", type=int, default=3, help="3 = RGB as the reference feeds SGBM, 1 = gray")
     ap.add_argument("--mode", default="sgbm", choices=["sgbm", "hh"],
                     help="sgbm = 5-path MODE_SGBM (the reference's call), hh = 8-path MODE_HH")
-    ap.add_argument("--path", type=int, default=0, help="0 = fused band-wavefront passes, 1 = one scan per direction")
+    ap.add_argument("--path", type=int, default=0, help="aggregation path: 0 auto, 1 scans, 2 band passes, 3 concurrent")
+    ap.add_argument("--cost", type=int, default=0, help="cost-volume kernels: 0 auto (fused), 1 fused k_cost, 2 k_hsum + k_vsum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary (other mode / gray) measurements")
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="strips in the CPU baseline sample (0 = one per thread)")
-    return ap.parse_args()
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (other mode, gray, PCIe)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="strips in the CPU baseline sample (0 = two per thread)")
+    ap.add_argument("--lib", default="", help="measurement only: load this build of libcalibrating_amd.so (A/B kernels)")
+    return ap.parse_args(argv)
 
 
-def sgbm_params(a, mode=None):
-    cn, bs = a.channels, a.block
+def sgbm_params(a, mode=None, channels=None):
+    cn, bs = (a.channels if channels is None else channels), a.block
     mode = a.mode if mode is None else mode
     return dict(minDisparity=0, numDisparities=a.disparities, blockSize=bs, P1=8 * cn * bs * bs,
                 P2=32 * cn * bs * bs, disp12MaxDiff=1, preFilterCap=0, uniquenessRatio=10,
@@ -63,91 +74,165 @@ def algorithmic_bytes_per_pair(W, H, D, cn, minD=0):
     return 2 * V + 2 * H * W * cn + 2 * H * W, V
 
 
+# stage (hipEvent bracket inside the library) -> (kernel it times, algorithmic HBM bytes per pair as f(V, HW, cn),
+# substrings that identify the kernel in a rocprofv3 summary)
+def stage_table(V, HW, cn, mode):
+    last = "k_band last pass (%s + WTA: C and S in)" % ("4 directions" if mode == "hh" else "1 direction")
+    return {
+        "cost": ("k_cost (BT cost + KxK box sum -> C, fused)", V + 2 * HW * cn, ("k_cost",)),
+        "hsum": ("k_hsum (BT cost + horizontal box sum)", V + 2 * HW * cn, ("k_hsum",)),
+        "vsum": ("k_vsum (vertical box sum + P2 -> C)", 2 * V, ("k_vsum",)),
+        "scan": ("k_band first pass (4 directions: C in, S out)", 2 * V, ("k_band", ", true, 0,")),
+        "scan_last": (last, 2 * V, ("k_band", ", 2,")),
+        "wta": ("k_lrcheck", 12 * HW, ("k_lrcheck",)),
+        "median_speckle": ("k_median3", 4 * HW, ("k_median3",)),
+    }
+
+
 def cpu_baseline(a, params):
-    """The CPU oracle (scalar C port of cv2.StereoSGBM, oracle/sgbm_ref.c) on this host's cores."""
+    """The CPU oracle (scalar C port of cv2.StereoSGBM, oracle/sgbm_ref.c) on ALL of this host's cores."""
     import oracle
     from calibrating_amd import synthetic
     oracle.build()
-    threads = min(os.cpu_count() or 1, 32)
-    n = a.cpu_pairs or threads
+    ncpu = os.cpu_count() or 1
+    threads = ncpu
     # bounded sample (~10-30 s of CPU work): full-width strips of half the rows (SGBM cost is linear in
     # rows), two strips per thread; scaled back to whole pairs below
-    frac = 2
-    hs = max(a.height // frac, 16)
-    n = n * 2 if not a.cpu_pairs else n
+    hs = max(a.height // 2, 16)
+    if a.mode == "hh":  # the two-pass mode keeps two whole strip volumes per thread: bound the host memory (32 GB)
+        vol = 2 * 2 * hs * max(a.width - a.disparities, 1) * a.disparities
+        threads = max(1, min(threads, int(32e9 // vol)))
+    n = a.cpu_pairs or 2 * threads
     base_l, base_r = synthetic.rectified_pair(seed=1234, H=hs, W=a.width, D=a.disparities, cn=a.channels)
-    lefts, rights = [], []
-    for i in range(n):  # distinct strips: vertical rolls of one generated strip
-        lefts.append(np.roll(base_l, 17 * i, axis=0))
-        rights.append(np.roll(base_r, 17 * i, axis=0))
-    L, R = np.stack(lefts), np.stack(rights)
+    L = np.stack([np.roll(base_l, 17 * i, axis=0) for i in range(n)])  # distinct strips: vertical rolls
+    R = np.stack([np.roll(base_r, 17 * i, axis=0) for i in range(n)])
     t0 = time.perf_counter()
     oracle.sgbm_compute_batch(L, R, nthreads=threads, **params)
     dt = time.perf_counter() - t0
     pairs = n * hs / a.height
-    return dict(value=pairs / dt, unit="pairs/s", cores=threads, kind="port",
+    return dict(value=pairs / dt, unit="pairs/s", cores=threads, host_cpu_count=ncpu, kind="port",
                 sample="%d strips of %dx%d (= %.2f pairs of %dx%d) D=%d cn=%d mode=%s, scalar C port "
-                       "oracle/sgbm_ref.c, %d OpenMP threads across strips, %.1f s"
+                       "oracle/sgbm_ref.c, %d OpenMP threads across strips (os.cpu_count() = %d), %.1f s; "
+                       "cv2 itself is not installed on this box"
                        % (n, a.width, hs, pairs, a.width, a.height, a.disparities, a.channels, a.mode,
-                          threads, dt))
+                          threads, ncpu, dt))
 
 
-def timed_steps(matcher, left, right, out, steps, warmup, barrier=None):
-    """K timed steps bracketed by barrier + synchronize; returns (seconds, {stage: ms summed})."""
+def gpu_steps(matcher, left, right, out, steps, warmup, distributed=False):
+    """(seconds, {stage: ms summed over the timed steps}) -- parallel_pairs.timed_steps around compute()."""
     import torch
-    for _ in range(warmup):
-        matcher.compute(left, right, out=out)
+    from calibrating_amd.parallel_pairs import timed_steps
     stage_ms = {}
-    if barrier:
-        barrier()
+
+    def step():
+        matcher.compute(left, right, out=out)
+
+    def timed_step():
+        matcher.compute(left, right, out=out)
+        for k, v in matcher.stage_times_ms().items():  # hipEvents on the compute stream, read after the fact
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
+
+    timed_steps(step, 0, warmup, torch.cuda.synchronize, False)
+    dt = timed_steps(timed_step, steps, 0, torch.cuda.synchronize, distributed)
+    return dt, stage_ms
+
+
+def pcie_inclusive(matcher, left, right, out, steps):
+    """pairs/s when every step's inputs come from (pinned) host memory and its disparities go back to it:
+    H2D of step k+1 and D2H of step k-1 overlap the compute of step k on three streams, two device buffers."""
+    import torch
+    nb = left.shape[0]
+    hl, hr = left.cpu().pin_memory(), right.cpu().pin_memory()
+    ho = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+    dl = [left, torch.empty_like(left)]
+    dr = [right, torch.empty_like(right)]
+    do = [out, torch.empty_like(out)]
+    s_in, s_out, s_cmp = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
+    ev_in = [torch.cuda.Event() for _ in range(2)]
+    ev_cmp = [torch.cuda.Event() for _ in range(2)]
+    ev_out = [torch.cuda.Event() for _ in range(2)]
+
+    def run(k):
+        b = k & 1
+        with torch.cuda.stream(s_in):
+            s_in.wait_event(ev_cmp[b])        # buffer b's previous compute has consumed its inputs
+            dl[b].copy_(hl, non_blocking=True)
+            dr[b].copy_(hr, non_blocking=True)
+            ev_in[b].record(s_in)
+        s_cmp.wait_event(ev_in[b])
+        s_cmp.wait_event(ev_out[b])           # buffer b's previous result has left
+        matcher.compute(dl[b], dr[b], out=do[b])
+        ev_cmp[b].record(s_cmp)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(ev_cmp[b])
+            ho.copy_(do[b], non_blocking=True)
+            ev_out[b].record(s_out)
+
+    for k in range(2):
+        run(k)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        matcher.compute(left, right, out=out)
-        for k, v in matcher.stage_times_ms().items():  # hipEvents on the compute stream
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    for k in range(steps):
+        run(k)
     torch.cuda.synchronize()
-    if barrier:
-        barrier()
-    return time.perf_counter() - t0, stage_ms
+    dt = time.perf_counter() - t0
+    bytes_per_pair = (hl[0].numel() + hr[0].numel()) + ho[0].numel() * 2
+    return dict(pairs_per_s=nb * steps / dt, host_bytes_per_pair=bytes_per_pair,
+                host_link_GBs=bytes_per_pair * nb * steps / dt / 1e9,
+                note="pinned host buffers, H2D + compute + D2H overlapped on 3 streams, %d steps of %d pairs" % (steps, nb))
 
 
-def _kernel_line(ms, nbytes):
-    return {"avg_ms_per_launch": ms, "algorithmic_bytes_per_launch": float(nbytes),
-            "achieved": (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else None, "unit": "GB/s"}
+def self_launch(a):
+    """--gpus N > 1 without a launcher: run N ranks of this script under torch.distributed.run."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to report a "
+                         "multi-GPU number from fewer devices\n" % (a.gpus, have))
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        self_launch(a)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        a.gpus = world
+    if "RANK" in os.environ and a.gpus not in (1, world):
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # CAMD_BENCH_FORCE_DIST=1 exercises the RCCL path (init, table broadcast, barrier, all-reduce) with a
+    # CAMD_BENCH_FORCE_DIST=1 exercises the RCCL path (init, table broadcast, barrier, reductions) with a
     # single rank, e.g. under `python -m torch.distributed.run --nproc-per-node 1`
     distributed = world > 1 or (os.environ.get("CAMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ["NCCL_DEBUG"] = os.environ.get("CAMD_NCCL_DEBUG", "WARN")  # keep RCCL's banner off stdout
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if a.lib:
+        from calibrating_amd import _native
+        _native.LIB_PATH = os.path.abspath(a.lib)
     import calibrating_amd as ca
     from calibrating_amd import synthetic
-    from calibrating_amd.parallel_pairs import broadcast_tables, shard_range
+    from calibrating_amd.parallel_pairs import aggregate, broadcast_tables, ranks_agree, shard_range
 
     params = sgbm_params(a)
-    # one-time table broadcast (rank 0 owns the rig; every rank needs maps + mask for get_depth)
-    if distributed:
-        bundle = ca.Stereo.load(synthetic.rig(a.width, a.height)).table_bundle() if rank == 0 else None
-        tables = broadcast_tables(bundle, dev, src=0)
-        del tables
-
     # this rank's shard of the global pair list: pairs [lo, hi) of world*batch
     lo, hi = shard_range(world * a.batch, world, rank)
     nb = hi - lo
@@ -156,83 +241,100 @@ def main():
     matcher = ca.StereoSGBM_create(**params)
     matcher.set_profiling(True)
     matcher.set_option("path", a.path)
+    matcher.set_option("cost", a.cost)
     out = torch.empty((nb, a.height, a.width), dtype=torch.int16, device=dev)
 
-    dt, stage_ms = timed_steps(matcher, left, right, out, a.steps, a.warmup, dist.barrier if distributed else None)
+    dt, stage_ms = gpu_steps(matcher, left, right, out, a.steps, a.warmup, distributed)
     matcher.status()  # raises if a device-side bounded wait timed out
+    checksum = int(out.to(torch.int64).sum().item())
+    agg = aggregate(nb * a.steps, dt, checksum, dev, distributed)
+    value = agg["total_pairs"] / agg["seconds"]
+
+    rccl = None
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        cs = torch.tensor([float(out.to(torch.int64).sum().item())], dtype=torch.float64, device=dev)
-        dist.all_reduce(cs)  # checksum of checksums: touches every rank's result
-    total_pairs = world * a.batch * a.steps
-    value = total_pairs / dt
+        # one-time table broadcast (rank 0 owns the rig), installed into every rank's Stereo; then every rank runs
+        # the full get_depth on the SAME two pairs through the broadcast tables and the ranks compare checksums
+        t0 = time.perf_counter()
+        rig_dict = synthetic.rig(a.width, a.height)
+        bundle = ca.Stereo.load(rig_dict).table_bundle() if rank == 0 else None
+        tables = broadcast_tables(bundle, dev, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+        stereo = ca.Stereo.load(rig_dict).install_tables(tables, dev)
+        stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(params, max_size=max(a.width, a.height))),
+                                   max_depth=20.0)
+        imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(im)) for im in
+                            synthetic.scene_pair(77, a.width, a.height, 3)]).to(dev)
+        res = stereo.get_depth_batch(imgs[:1].repeat(2, 1, 1, 1), imgs[1:].repeat(2, 1, 1, 1))
+        dsum = int(torch.nan_to_num(res["unrectify_depth"]).mul(1e4).round().to(torch.int64).sum().item())
+        rccl = dict(backend="nccl (RCCL)", world_size=world, table_bytes=int(sum(t.numel() * t.element_size()
+                                                                                  for t in tables.values())),
+                    broadcast_s=t_bcast, get_depth_checksum=dsum, ranks_agree=bool(ranks_agree(dsum, dev)),
+                    per_rank=[dict(pairs=p, seconds=s, disparity_checksum=c) for p, s, c in agg["per_rank"]])
+        del stereo, tables, res, imgs
 
     also = {}
     if rank == 0 and world == 1 and not a.no_also:
+        k2 = max(3, min(a.steps, 10))
+        also["pcie_inclusive"] = pcie_inclusive(matcher, left, right, out, k2)
         del matcher
         # the other aggregation mode on the same inputs, and the gray variant of the headline mode
         other = "hh" if a.mode == "sgbm" else "sgbm"
         m2 = ca.StereoSGBM_create(**sgbm_params(a, other))
         m2.set_profiling(True)
         m2.set_option("path", a.path)
-        d2, _ = timed_steps(m2, left, right, out, a.steps, 1)
-        also["%s_%s_pairs_per_s" % ("rgb" if a.channels == 3 else "gray", other)] = nb * a.steps / d2
+        m2.set_option("cost", a.cost)
+        d2, _ = gpu_steps(m2, left, right, out, k2, 1)
+        also["%s_%s_pairs_per_s" % ("rgb" if a.channels == 3 else "gray", other)] = nb * k2 / d2
         del m2
         if a.channels == 3:
-            g = argparse.Namespace(**vars(a))
-            g.channels = 1
-            m3 = ca.StereoSGBM_create(**sgbm_params(g))
+            m3 = ca.StereoSGBM_create(**sgbm_params(a, channels=1))
             m3.set_profiling(True)
             m3.set_option("path", a.path)
+            m3.set_option("cost", a.cost)
             gl, gr = left[..., 1].contiguous(), right[..., 1].contiguous()
-            d3, _ = timed_steps(m3, gl, gr, out, a.steps, 1)
-            also["gray_%s_pairs_per_s" % a.mode] = nb * a.steps / d3
+            d3, _ = gpu_steps(m3, gl, gr, out, k2, 1)
+            also["gray_%s_pairs_per_s" % a.mode] = nb * k2 / d3
             del m3, gl, gr
 
     if rank == 0:
         b_alg, V = algorithmic_bytes_per_pair(a.width, a.height, a.disparities, a.channels)
+        table = stage_table(V, a.width * a.height, a.channels, a.mode)
         gpu_ms_step = sum(stage_ms.values()) / a.steps
-        achieved = b_alg * nb / (gpu_ms_step * 1e-3) / 1e9
-        if a.path == 0:
-            # fused band passes (both modes): pass 1 reads C, writes S; pass 2 reads C and S (+ WTA).  The two are
-            # different kernels, timed separately; the roofline block prices the slower (dominant) one.
-            ms1 = stage_ms.get("scan", 0.0) / a.steps
-            ms2 = stage_ms.get("scan_last", 0.0) / a.steps
-            first_dominant = ms1 >= ms2
-            k_ms = ms1 if first_dominant else ms2
-            npass = 1
-            vols = 2
-            kname = ("k_band first pass (four directions: C in, S out)" if first_dominant else
-                     "k_band last pass (%s + WTA: C and S in)" % ("four directions" if a.mode == "hh" else "one direction"))
-            other = {"kernel": "k_band last pass" if first_dominant else "k_band first pass",
-                     "avg_ms_per_launch": ms2 if first_dominant else ms1,
-                     "achieved": (2 * V * nb / ((ms2 if first_dominant else ms1) * 1e-3) / 1e9) if min(ms1, ms2) > 0 else None}
-        else:
-            npass = 8 if a.mode == "hh" else 5
-            vols = 3 * npass - 1
-            kname = "k_scan (one aggregation direction)"
-            k_ms = (stage_ms.get("scan", 0.0) + stage_ms.get("scan_last", 0.0)) / a.steps / npass
-            other = None
-        k_bytes = vols / npass * V * nb
-        # HBM traffic per launch from the committed PMC profile of the same kernels (separate rocprofv3
-        # --pmc passes, 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction); null when no profile matches
-        traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic%s.json" % ("_hh" if a.mode == "hh" else ""))
-        if (a.path == 0 and a.channels == 3 and (a.width, a.height, a.disparities) == (1920, 1080, 128)
+        # HBM traffic per kernel from the committed PMC profile of the same kernels (separate rocprofv3 --pmc
+        # passes, 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction); null when no profile matches this workload
+        pmc_path = os.path.join(ROOT, PMC_PROFILE % ("_hh" if a.mode == "hh" else ""))
+        pmc = None
+        if (a.channels == 3 and (a.width, a.height, a.disparities, a.block) == (1920, 1080, 128, 5)
                 and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))
-            # the dominant kernel's entry: first pass = k_band<.., true, 0, ..>, last pass = k_band<.., false|true, 2, ..>
-            want = ", true, 0," if first_dominant else ", 2,"
-            per_pair = [v["hbm_bytes_per_pair"] for k, v in pmc["kernels"].items() if "k_band" in k and want in k]
-            if per_pair:
-                traffic = per_pair[0] * nb
-                traffic_src = "profiles/%s (bytes per pair per launch x pairs per launch)" % os.path.basename(pmc_path)
+
+        def pmc_bytes_per_pair(keys):
+            if not pmc:
+                return None
+            hit = [v["hbm_bytes_per_pair"] for k, v in pmc["kernels"].items() if all(s in k for s in keys)]
+            return hit[0] if len(hit) == 1 else None
+
+        kernels = {}
+        for st, ms_sum in stage_ms.items():
+            ms = ms_sum / a.steps
+            if st not in table or ms <= 0:
+                continue
+            name, per_pair, keys = table[st]
+            tr = pmc_bytes_per_pair(keys)
+            ach = per_pair * nb / (ms * 1e-3) / 1e9
+            kernels[st] = {"kernel": name, "avg_ms_per_launch": ms, "algorithmic_bytes_per_launch": float(per_pair * nb),
+                           "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": (tr * nb) if tr is not None else None}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms_per_launch"]) if kernels else None
+        traffic_total = None
+        if pmc and kernels and all(v["traffic"] is not None for k, v in kernels.items() if k in ("cost", "hsum", "vsum", "scan", "scan_last")):
+            traffic_total = sum(v["traffic"] for v in kernels.values() if v["traffic"] is not None)
+        achieved = b_alg * nb / (gpu_ms_step * 1e-3) / 1e9
         line = {
             "metric": "stereo pairs/s at 1920x1080 numDisparities=128",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": agg["seconds"] / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "cv2.StereoSGBM-equivalent disparity of %dx%d rectified %s pairs, "
                                    "numDisparities=%d blockSize=%d mode=%s, median3 on, speckle off"
@@ -240,31 +342,31 @@ def main():
                                       a.block, "MODE_HH(8 paths)" if a.mode == "hh" else "MODE_SGBM(5 paths)"),
                        "pairs_per_gpu_per_step": a.batch, "global_pairs_per_step": world * a.batch,
                        "parallelism": "pairs sharded over %d GPU(s), no data-path collective" % world},
+            # Headline = SURVEY section 8(d): B_alg x pairs per step / GPU time of one step (sum of the kernels'
+            # hipEvent durations on the compute stream of rank 0), against the 8 TB/s HBM peak.  `dominant_kernel`
+            # is the kernel with the largest measured launch duration, priced with ITS algorithmic bytes; every
+            # number can be recomputed from profiles/r02_*kernel_stats.csv and profiles/r02_pmc_traffic*.json.
             "roofline": {
-                "bound": "hbm", "kernel": kname,
-                "achieved": k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else None,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "launches_per_step": npass, "avg_ms_per_launch": k_ms, "other_band_pass": other,
-                # the rest of the pipeline, same accounting (algorithmic HBM bytes per launch / measured time)
-                "other_kernels": {
-                    "k_hsum (BT cost + horizontal box sum; VALU-bound)": _kernel_line(
-                        stage_ms.get("hsum", 0.0) / a.steps, (V + 2 * a.width * a.height * a.channels) * nb),
-                    "k_vsum (vertical box sum)": _kernel_line(stage_ms.get("vsum", 0.0) / a.steps, 2 * V * nb),
-                },
-                "algorithmic_bytes_per_launch": k_bytes,
-                "stage_ms_per_step": {k: v / a.steps for k, v in stage_ms.items()},
-                "pipeline": {"algorithmic_bytes_per_pair": b_alg, "gpu_ms_per_step": gpu_ms_step,
-                             "achieved": achieved, "frac": achieved / HBM_PEAK_GBS},
+                "bound": "hbm", "scope": "whole step (all kernels of one batch)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_pair": b_alg, "algorithmic_bytes_per_launch": float(b_alg * nb),
+                "gpu_ms_per_step": gpu_ms_step,
+                "traffic": traffic_total,
+                "traffic_ratio": (traffic_total / (b_alg * nb)) if traffic_total else None,
+                "traffic_source": (PMC_PROFILE % ("_hh" if a.mode == "hh" else "")) + " (bytes per pair per launch x pairs per launch)" if pmc else None,
+                "dominant_kernel": dict(kernels[dom], stage=dom) if dom else None,
+                "kernels": kernels,
             },
         }
         if also:
             line["also"] = also
+        if rccl:
+            line["rccl"] = rccl
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a, params)
         print(json.dumps(line))
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,22 +1,54 @@
 """``Cam``: the per-camera record ``Stereo`` needs -- K, D, xy, name.
 
-Only the ``Cam.load`` path of the reference (/root/reference/calibrating/camera.py:424-448) is
-mirrored: intrinsic calibration itself (cv2.calibrateCamera, boards, caches) is outside the
-stereo-depth hot path.
+Only the record format of the reference's ``Cam`` is mirrored (``Cam.load`` / ``Cam.dump``,
+/root/reference/calibrating/camera.py:407-448): a YAML / dict record with either ``K`` (3x3) or
+``fx, fy, cx, cy``, optional ``D`` (default five zeros), ``xy`` = (width, height) (required), and the
+free-form keys ``name``, ``T_in_main_cam``, ``retval``.  Intrinsic calibration itself
+(cv2.calibrateCamera, boards, caches) is outside the stereo-depth hot path.
 """
 import copy
 
 import numpy as np
 import yaml
 
+_INTRINSIC_KEYS = ("fx", "fy", "cx", "cy")
+_RECORD_KEYS = ("D", "xy", "name", "T_in_main_cam", "retval")  # what a dump carries besides the intrinsics
+
 
 def intrinsic_format_conversion(K_or_dic):
-    """K (3x3) <-> dict(fx, fy, cx, cy)  (camera.py dump/load format)."""
+    """K (3x3) <-> dict(fx, fy, cx, cy): the two spellings of the intrinsics in a camera record."""
     if isinstance(K_or_dic, dict):
-        d = K_or_dic
-        return np.array([[d["fx"], 0, d["cx"]], [0, d["fy"], d["cy"]], [0, 0, 1]], np.float64)
+        fx, fy, cx, cy = (K_or_dic[k] for k in _INTRINSIC_KEYS)
+        return np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
     K = np.asarray(K_or_dic)
-    return dict(fx=float(K[0, 0]), fy=float(K[1, 1]), cx=float(K[0, 2]), cy=float(K[1, 2]))
+    return {k: float(v) for k, v in zip(_INTRINSIC_KEYS, (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))}
+
+
+def read_record(source):
+    """A record from a dict (deep-copied), a YAML document (a string containing a newline) or a YAML file
+    path -- the three input forms ``Cam.load`` / ``Stereo.load`` of the reference accept."""
+    if isinstance(source, (dict, list)):
+        return copy.deepcopy(source)
+    if "\n" in source:
+        return yaml.safe_load(source)
+    with open(source) as f:
+        return yaml.safe_load(f)
+
+
+def write_record(record, path=""):
+    """YAML text of ``record`` stamped with the package version; also written to ``path`` when given."""
+    from .__info__ import __version__
+    text = yaml.safe_dump(dict(record, _calibrating_version=__version__))
+    if path:
+        with open(path, "w") as f:
+            f.write(text)
+    return text
+
+
+def _plain(value):
+    if isinstance(value, np.ndarray):
+        return value.tolist()
+    return list(value) if isinstance(value, tuple) else value
 
 
 class Cam(dict):
@@ -33,49 +65,32 @@ class Cam(dict):
         return cls(K, D, xy, name)
 
     def load(self, path_or_str_or_dict=None):
-        if path_or_str_or_dict is None:
-            path_or_str_or_dict = self
-            self = Cam()
+        """``Cam.load(record)`` (called on the class: builds a new Cam) or ``cam.load(record)`` (in place)."""
+        if path_or_str_or_dict is None:  # Cam.load(x) binds x to `self`
+            return Cam().load(self)
         if isinstance(path_or_str_or_dict, Cam):
             return path_or_str_or_dict.copy()
-        if not isinstance(path_or_str_or_dict, (list, dict)):
-            path_or_str = path_or_str_or_dict
-            if "\n" in path_or_str:
-                dic = yaml.safe_load(path_or_str)
-            else:
-                with open(path_or_str) as f:
-                    dic = yaml.safe_load(f)
+        rec = read_record(path_or_str_or_dict)
+        rec.pop("_calibrating_version", None)
+        if "K" in rec:
+            K = rec.pop("K")
         else:
-            dic = copy.deepcopy(path_or_str_or_dict)
-        if "K" not in dic:
-            dic["K"] = intrinsic_format_conversion(dic)
-            [dic.pop(k) for k in ("fx", "fy", "cx", "cy")]
-        dic["K"] = np.float64(dic["K"])
-        dic["D"] = np.float64(dic["D"]) if "D" in dic else np.zeros((1, 5))
-        dic["xy"] = tuple(dic.get("xy", getattr(self, "xy", "")))
-        assert len(dic["xy"]), "Need xy"
-        dic.pop("_calibrating_version", None)
-        self.__dict__.update(dic)
+            K = intrinsic_format_conversion({k: rec.pop(k) for k in _INTRINSIC_KEYS})
+        xy = tuple(rec.pop("xy", getattr(self, "xy", ())))
+        assert len(xy), "Need xy"
+        self.K = np.float64(K)
+        self.D = np.float64(rec.pop("D")) if "D" in rec else np.zeros((1, 5))
+        self.xy = xy
+        self.__dict__.update(rec)
         return self
 
     def copy(self):
-        new = type(self)()
-        new.load(self.dump(return_dict=True))
-        return new
+        return type(self)().load(self.dump(return_dict=True))
 
     def dump(self, path="", return_dict=False):
-        dic = {k: v.tolist() if isinstance(v, np.ndarray) else (list(v) if isinstance(v, tuple) else v)
-               for k, v in self.__dict__.items() if k in ["D", "xy", "name", "T_in_main_cam", "retval"]}
-        dic.update(intrinsic_format_conversion(self.K))
-        if return_dict:
-            return dic
-        from .__info__ import __version__
-        dic["_calibrating_version"] = __version__
-        yamlstr = yaml.safe_dump(dic)
-        if path:
-            with open(path, "w") as f:
-                f.write(yamlstr)
-        return yamlstr
+        rec = {k: _plain(self.__dict__[k]) for k in _RECORD_KEYS if k in self.__dict__}
+        rec.update(intrinsic_format_conversion(self.K))
+        return rec if return_dict else write_record(rec, path)
 
     def project_cam2_depth(cam1, cam2, depth2, T=None, interpolation=1.5):
         """Depth image of ``cam2`` re-projected into this camera (camera.py:298-309), on the GPU.

@@ -99,15 +99,9 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
     };
     const uint8_t* imgR = right + (size_t)pair * image_stride;
     const uint8_t* imgL = left + (size_t)pair * image_stride;
-#ifdef CAMD_DBG_HSUM_NOSTAGE
-    if (g.W == -1)
-#endif
     for (int e = threadIdx.x; e < ncols + 2; e += blockDim.x)
 #pragma unroll
         for (int c = 0; c < CN; c++) stage[e * ES + c * 3] = plane(imgR, colbase - 1 + e, c);
-#ifdef CAMD_DBG_HSUM_NOSTAGE
-    if (g.W == -1)
-#endif
     for (int e = threadIdx.x; e < nleft + 2; e += blockDim.x)
 #pragma unroll
         for (int c = 0; c < CN; c++) lstage[e * ES + c * 3] = plane(imgL, clo + g.minX1 - 1 + e, c);
@@ -124,13 +118,7 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
             dst[e * ES + c * 3 + 2] = pk_max_u16(pk_max_u16(ul, ur), u);
         }
     };
-#ifdef CAMD_DBG_HSUM_NOSTAGE
-    if (g.W == -1)
-#endif
     for (int i = threadIdx.x; i < ncols; i += blockDim.x) finish(stage, i + 1, colbase + i);
-#ifdef CAMD_DBG_HSUM_NOSTAGE
-    if (g.W == -1)
-#endif
     for (int i = threadIdx.x; i < nleft; i += blockDim.x) finish(lstage, i + 1, clo + g.minX1 + i);
     __syncthreads();
     const uint4* lent = reinterpret_cast<const uint4*>(lstage) + (ES / 4);  // skip the halo entry
@@ -145,11 +133,7 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
     struct Ops { uint32_t V[CN], V0[CN], V1[CN], U[CN], U0[CN], U1[CN]; };
     auto fetch = [&](int t, Ops& o) {
         const int ct = min(max(t, 0), g.W1 - 1);  // clamped virtual column (box sum replicates the border)
-#ifdef CAMD_DBG_HSUM_NORIGHT
-        const uint4* e = ent;
-#else
         const uint4* e = ent + (size_t)(ct - clo) * (ES / 4);
-#endif
         if (CN == 1) {
             uint4 a = e[0];
             o.V[0] = a.x; o.V0[0] = a.y; o.V1[0] = a.z;
@@ -190,12 +174,7 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
     };
     auto emit = [&](int t) {
         const int xo = t - g.SW2;
-#ifdef CAMD_DBG_HSUM_NOSTORE  // measurement variant (never part of the product build)
-        asm volatile("" ::"v"(run));
-        if (xo == -12345)
-#else
         if (xo >= xs)
-#endif
             out[(size_t)xo * g.Dp] = (uint16_t)(run & vmask);  // one unconditional store: no exec juggling
     };
     Ops A, B;
@@ -636,10 +615,12 @@ struct camd_sgbm {
     bool band_ok;         // geometry supported by k_band instantiations
     int path;             // 0 = band passes (default when band_ok), 1 = one k_scan per direction
     int keep_S;           // band path: also store S in the final pass (stage-wise parity hook)
+    int cost_path;        // CAMD_COST_*
     int nbands, nchunks;
     size_t erec_stride;
     unsigned long long* E;
     uint32_t *flags, *ticket, *err, *keys;
+    uint32_t* err_host;   // pinned mirror of *err, refreshed by an async copy after every band-path compute
     int16_t* d1;
     uint32_t epoch;
     uint16_t* Smulti;     // concurrent-direction path: npaths volumes per pair, allocated on first use
@@ -781,8 +762,6 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     a.sx = sx; a.sy = sy; a.nbands = h->nbands; a.nchunks = h->nchunks; a.npairs = batch;
     a.epoch = ++h->epoch;
     a.write_S = h->keep_S;
-    static const int nodep = getenv("CAMD_BAND_NODEP") ? atoi(getenv("CAMD_BAND_NODEP")) : 0;
-    a.nodep = nodep;
     CAMD_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
     dim3 grid(h->nbands * batch), block(BAND_BLOCK);
     const bool pad = g.Dp != g.D;
@@ -882,6 +861,8 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         if (e == hipSuccess) e = hipMemset(h->flags, 0, nflags * 4);
         if (e == hipSuccess) e = hipMemset(h->ticket, 0, 8);
         h->err = h->ticket + 1;
+        if (e == hipSuccess) e = hipHostMalloc((void**)&h->err_host, 4, hipHostMallocDefault);
+        if (e == hipSuccess) *h->err_host = 0;
     }
     if (e != hipSuccess) {
         set_error("workspace allocation failed: %s", hipGetErrorString(e));
@@ -901,6 +882,7 @@ int camd_sgbm_destroy(camd_sgbm* h)
     (void)hipFree(h->raw); (void)hipFree(h->speckle_ws);
     (void)hipFree(h->E); (void)hipFree(h->flags); (void)hipFree(h->ticket); (void)hipFree(h->keys);
     (void)hipFree(h->d1); (void)hipFree(h->Smulti);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     delete h;
     return CAMD_OK;
 }
@@ -920,6 +902,7 @@ int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
     if (!h) { set_error("handle is NULL"); return CAMD_ERR_BAD_ARG; }
     if (option == CAMD_OPT_PATH && value >= CAMD_PATH_AUTO && value <= CAMD_PATH_CONCURRENT) h->path = value;
     else if (option == CAMD_OPT_KEEP_S) h->keep_S = value != 0;
+    else if (option == CAMD_OPT_COST && value >= CAMD_COST_AUTO && value <= CAMD_COST_SPLIT) h->cost_path = value;
     else { set_error("unknown option %d / value %d", option, value); return CAMD_ERR_BAD_ARG; }
     return CAMD_OK;
 }
@@ -933,7 +916,9 @@ int camd_sgbm_status(camd_sgbm* h, void* stream)
     CAMD_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (e) {
         CAMD_HIP(hipMemsetAsync(h->err, 0, 4, (hipStream_t)stream));
-        set_error("a band-wavefront pass timed out waiting for its upstream band");
+        if (h->err_host) *(volatile uint32_t*)h->err_host = 0;
+        set_error("a band-wavefront pass timed out waiting for its upstream band; the disparities of that call "
+                  "were written as invalid");
         return CAMD_ERR_HIP;
     }
     return CAMD_OK;
@@ -975,6 +960,16 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         return CAMD_ERR_BAD_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
+    // A device-side bounded wait that expired in an EARLIER call (its result was written as all-invalid by
+    // k_lrcheck) is reported here without a synchronisation: the flag travels through a pinned mirror that an
+    // async copy refreshes at the end of every band-path compute.
+    if (h->err_host && *(volatile uint32_t*)h->err_host) {
+        *(volatile uint32_t*)h->err_host = 0;
+        CAMD_HIP(hipMemsetAsync(h->err, 0, 4, st));
+        set_error("an earlier compute on this handle timed out in a band-wavefront pass (its disparities were "
+                  "written as invalid)");
+        return CAMD_ERR_HIP;
+    }
     const size_t dpe = disp_pitch / 2, dse = disp_stride / 2;
     const bool prof = h->profiling && h->ev_ok;
 #define MARK(i) do { if (prof) CAMD_HIP(hipEventRecord(h->ev[i], st)); } while (0)
@@ -1095,8 +1090,9 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     MARK(ST_WTA);
     if (band) {
         hipLaunchKernelGGL(k_lrcheck, dim3(div_up(g.W, 256), g.H, batch), dim3(256), 0, st, h->d1, h->keys, h->raw,
-                           (size_t)g.W, raw_stride, g);
+                           (size_t)g.W, raw_stride, g, h->err);
         CAMD_LAUNCH_CHECK();
+        CAMD_HIP(hipMemcpyAsync(h->err_host, h->err, 4, hipMemcpyDeviceToHost, st));
     } else {
         int rc = multi ? launch_wta(h, h->Smulti, g.npaths, dir_stride, h->raw, (size_t)g.W, raw_stride, batch, st)
                        : launch_wta(h, h->S, 1, 0, h->raw, (size_t)g.W, raw_stride, batch, st);

@@ -56,7 +56,6 @@ struct BandArgs {
     int sx, sy, nbands, nchunks, npairs;
     uint32_t epoch;
     int write_S;            // FINAL only: also store S (stage-wise parity hook)
-    int nodep;              // measurement only (CAMD_BAND_NODEP=1): cut the band->band dependency (wrong results)
 };
 
 // one SGM update: L = C + min(Lp, Lp[d-1]+P1, Lp[d+1]+P1, delta) - delta, packed u16, returns new delta
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
     const bool rvalid = !helper && row < H;
     const int y = a.sy > 0 ? row : H - 1 - row;
     const int glast = min(R, H - band * R) - 1;
-    const bool has_prev = FULL && band > 0 && !a.nodep, has_next = FULL && band + 1 < a.nbands && !a.nodep;
+    const bool has_prev = FULL && band > 0, has_next = FULL && band + 1 < a.nbands;
     const bool producer = !helper && has_next && grp == glast;
 
     const uint32_t P1pk = dup16((uint32_t)g.P1), P2pk = dup16((uint32_t)g.P2);
@@ -467,11 +466,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
 #pragma unroll
                     for (int v = 0; v < NV; v++) sp[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
                 }
-#ifdef CAMD_DBG_BAND_NOWTA  // measurement variant (never part of the product build)
-                if (MODE == 2) asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]));
-#else
                 if (MODE == 2) band_wta_step<LANES, NV>(s, dpk, wS, g, grp, li, t, true, cap_key, cap_nb);
-#endif
             }
             if (MODE == 2 && ((t & (LANES - 1)) == LANES - 1 || t == nsteps - 1)) {
                 // lane li captured the pixel of step t - ((t mod LANES) - li)
@@ -524,7 +519,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
 // left-right check of one row from the candidates / right-view keys the FINAL band pass produced
 __global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ d1, const uint32_t* __restrict__ keys,
                                                  int16_t* __restrict__ out, size_t out_pitch_e, size_t out_stride_e,
-                                                 Geom g)
+                                                 Geom g, const uint32_t* __restrict__ err)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= g.W) return;
@@ -551,6 +546,9 @@ __global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ d1,
         }
         if (bad) v1 = INVALID_SCALED;
     }
+    // a band whose bounded wait expired computed on unpublished edge data: poison the whole result rather
+    // than hand back plausible-looking garbage (camd_sgbm_status / the next compute report the error)
+    if (*err) v1 = INVALID_SCALED;
     out[(size_t)pair * out_stride_e + (size_t)y * out_pitch_e + x] = (int16_t)v1;
 }
 

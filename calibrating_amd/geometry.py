@@ -13,7 +13,10 @@ eps = 1e-8
 
 
 def project_vec_on_plane(v, plane_v):
-    return v - np.dot(v, plane_v) / (np.linalg.norm(plane_v) ** 2) * plane_v
+    """Component of ``v`` inside the plane whose normal is ``plane_v`` (utils.py:139-140)."""
+    n = np.asarray(plane_v, np.float64)
+    v = np.asarray(v, np.float64)
+    return v - n * (np.dot(v, n) / np.linalg.norm(n) ** 2)
 
 
 def rodrigues(r):
@@ -53,12 +56,13 @@ def rodrigues(r):
 
 
 def rotate_shortest_of_two_vecs(v1, v2, return_rodrigues=False):
-    cross = np.cross(v1, v2)
-    rad = np.arccos((v1 * v2).sum() / np.linalg.norm(v1) / np.linalg.norm(v2))
-    r = rad * cross / (np.linalg.norm(cross) + eps)
-    if return_rodrigues:
-        return r
-    return rodrigues(r)
+    """Rotation taking the direction of ``v1`` onto ``v2`` about their common normal (utils.py:143-149):
+    axis = v1 x v2 normalised with the reference's ``+ eps`` in the denominator, angle = the angle between."""
+    a, b = np.asarray(v1, np.float64), np.asarray(v2, np.float64)
+    axis = np.cross(a, b)
+    angle = np.arccos(np.sum(a * b) / np.linalg.norm(a) / np.linalg.norm(b))
+    rvec = axis * (angle / (np.linalg.norm(axis) + eps))
+    return rvec if return_rodrigues else rodrigues(rvec)
 
 
 def inv3(m):
@@ -113,22 +117,96 @@ def init_undistort_rectify_map(A, dist, R, Anew, size):
 
 
 def R_t_to_T(R, t=None):
-    if t is None:
-        t = np.zeros((3,))
-    R = np.float32(R)  # the reference rounds R through float32 here (utils.py:18)
-    if R.size == 3:
-        R = rodrigues(np.float64(R).reshape(3))
-    T = np.zeros((4, 4))
-    T[:3, :3] = R
-    T[:3, -1] = np.array(t).squeeze()
-    T[3, 3] = 1
+    """4x4 pose from a rotation (matrix, or a 3-vector = Rodrigues) and a translation.  The reference
+    rounds the rotation argument through float32 first (utils.py:15-31); a 3-vector is converted after
+    that rounding and the resulting matrix rounded to float32 again, like cv2.Rodrigues on a float32 input."""
+    rot = np.asarray(R, np.float32)
+    if rot.size == 3:
+        rot = rodrigues(rot.astype(np.float64).reshape(3)).astype(np.float32)
+    T = np.eye(4)
+    T[:3, :3] = rot
+    if t is not None:
+        T[:3, 3] = np.asarray(t, np.float64).reshape(3)
     return T
 
 
 def T_to_r_t(T):
+    """(rvec (3,1), tvec (3,1)) of a 4x4 pose or a 3x3 rotation."""
     T = np.asarray(T, np.float64)
-    rvec = rodrigues(T[:3, :3])
-    tvec = T[:3, 3:]
-    if not tvec.size:
-        tvec = np.zeros((3, 1))
-    return rvec, tvec
+    tvec = T[:3, 3:4] if T.shape[1] > 3 else np.zeros((3, 1))
+    return rodrigues(T[:3, :3]), tvec
+
+
+# ---- rig-level pure functions (what Stereo's methods of the reference's names are thin wrappers of) -------------
+def rectifying_rotations(R, t):
+    """(R1, R2): rotations of camera 1 / camera 2 into the common rectified frame.
+
+    SURVEY.md section 3.2 (reference stereo_camera.py:199-214).  Frame of camera 2; ``R, t`` map camera-1
+    coordinates into it.  The rectified x axis is the baseline (-x onto t), the rectified z axis is the
+    bisector of the two optical axes after each has been projected into the plane normal to the baseline:
+        Rx = shortest rotation of -x onto t
+        Rz = shortest rotation of Rx.z onto that bisector
+        R2 = (Rz Rx)^T ,  R1 = R2 R
+    """
+    R = np.asarray(R, np.float64)[:3, :3]
+    base = np.asarray(t, np.float64).reshape(3)
+    ez = np.array([0.0, 0.0, 1.0])
+    in_plane = [project_vec_on_plane(axis, base) for axis in (ez, R @ ez)]  # camera 2's, camera 1's optical axis
+    bisector = sum(v / np.linalg.norm(v) for v in in_plane)
+    Rx = rotate_shortest_of_two_vecs(np.array([-1.0, 0.0, 0.0]), base)
+    Rz = rotate_shortest_of_two_vecs(Rx @ ez, bisector)
+    R2 = (Rz @ Rx).T
+    return R2 @ R, R2
+
+
+def _image_centre_shift(xy_cam, K_cam, R_rect, K_new):
+    """Where the centroid of a camera's four image corners lands in the rectified image, relative to the
+    rectified principal point (the ``get_center`` closure of stereo_camera.py:137-152)."""
+    w, h = xy_cam
+    corners = np.array([[0, 0, 1], [w, 0, 1], [w, h, 1], [0, h, 1]], np.float64)
+    rays = corners @ np.linalg.inv(K_cam).T @ R_rect.T
+    uvw = rays @ K_new.T
+    return (uvw[:, :2] / uvw[:, 2:]).mean(0) - K_new[:2, 2]
+
+
+def target_intrinsics(cam1_K, cam1_xy, cam2_K, cam2_xy, R1, R2, xy_target=None, K_target=1):
+    """(xy, K) of the rectified image pair (reference stereo_camera.py:125-156).
+
+    xy_target  None -> camera 1's size; a number scales it (each side rounded); else taken as (w, h).
+    K_target   a number s -> camera 1's K with the upper-left 2x2 times s and the principal point moved by
+               half the size change, then re-centred: the principal point is placed so that the mean of the
+               two cameras' projected image-corner centroids sits at the image centre ("better cx cy").
+               An ndarray is used as is (the same object, no re-centring).
+    """
+    if xy_target is None:
+        xy_target = cam1_xy
+    if isinstance(xy_target, (int, float)):
+        xy_target = [int(round(side * xy_target)) for side in cam1_xy]
+    xy = tuple(xy_target)
+    if isinstance(K_target, np.ndarray):
+        return xy, K_target
+    K = K_target
+    if isinstance(K_target, (int, float)):
+        K = np.array(cam1_K, np.float64)
+        K[:2, :2] *= K_target
+        K[:2, 2] += (np.array(xy) - cam1_xy) / 2
+    shift = (_image_centre_shift(cam1_xy, cam1_K, R1, K) + _image_centre_shift(cam2_xy, cam2_K, R2, K)) / 2
+    K[:2, 2] = np.array(xy) / 2 - shift
+    return xy, K
+
+
+def valid_mask_from_maps(mapx, mapy, xy_src):
+    """True where a remap source coordinate falls inside the source image (stereo_camera.py:166-176)."""
+    w, h = xy_src
+    return (mapx > -0.5) & (mapx < w - 0.5) & (mapy > -0.5) & (mapy < h - 0.5)
+
+
+def rig_rotation_from_record(rec):
+    """The rotation of a Stereo record: ``R`` (3x3), else ``T`` (4x4, also supplies ``t``), else ``r``
+    (Rodrigues vector), else identity (stereo_camera.py:287-292).  Mutates and returns ``rec``."""
+    if "R" not in rec and "T" in rec:
+        rec["r"], rec["t"] = T_to_r_t(np.asarray(rec.pop("T"), np.float64))
+    if "R" not in rec and "r" in rec:
+        rec["R"] = rodrigues(np.asarray(rec.pop("r"), np.float64).reshape(3))
+    rec.setdefault("R", np.eye(3))
+    return rec

@@ -1,10 +1,14 @@
 """Multi-GPU layer of the stereo path: independent pairs shard across ranks, tables are broadcast once.
 
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the
-CPU tests).  There is no per-pair communication: a rig's remap tables / validity mask (~52 MB at
-1080p) are broadcast from rank 0 once, then every rank runs ``Stereo.get_depth`` / ``StereoSGBM.compute``
-on its contiguous shard of the pair list.
+CPU tests).  There is no per-pair communication: a rig's remap tables / validity mask (~35 MB at
+1080p) are broadcast from rank 0 once and installed into every rank's ``Stereo``
+(``Stereo.install_tables``), then every rank runs ``Stereo.get_depth_batch`` / ``StereoSGBM.compute``
+on its contiguous shard of the pair list.  ``bench.py`` is built from the
+functions of this module, so the world_size-2 gloo test exercises the same code the RCCL run does.
 """
+import time
+
 import numpy as np
 
 
@@ -26,7 +30,8 @@ def broadcast_tables(bundle, device, src=0):
     """Broadcast the table bundle of ``Stereo.table_bundle()`` from ``src`` to every rank.
 
     ``bundle`` is the dict on ``src`` and ignored (may be None) elsewhere.  Shapes travel first in one
-    small int64 tensor, then one collective per table.  Returns a dict of tensors on ``device``.
+    small int64 tensor, then one collective per table.  Returns a dict of tensors on ``device``
+    (feed it to ``Stereo.install_tables``).
     """
     import torch
     import torch.distributed as dist
@@ -50,11 +55,60 @@ def broadcast_tables(bundle, device, src=0):
     return out
 
 
-def gather_throughput(pairs_done, seconds, device):
-    """all_gather of per-rank (pairs, seconds); returns (total_pairs, max_seconds)."""
+def timed_steps(step, steps, warmup, synchronize=None, distributed=False):
+    """``warmup`` untimed + exactly ``steps`` timed calls of ``step()``, bracketed by barrier +
+    ``synchronize()`` on both sides.  Returns this rank's seconds (reduce with ``aggregate``)."""
+    sync = synchronize or (lambda: None)
+    if distributed:
+        import torch.distributed as dist
+        barrier = dist.barrier
+    else:
+        barrier = lambda: None  # noqa: E731
+    for _ in range(warmup):
+        step()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def aggregate(pairs_done, seconds, checksum, device, distributed=True):
+    """End-of-run reduction: total pairs over ranks, MAX of the seconds, and the checksum of checksums
+    (sum over ranks of each rank's int64 result checksum -- touches every rank's output).
+
+    Returns dict(total_pairs, seconds, checksum, per_rank=[(pairs, seconds, checksum), ...])."""
+    if not distributed:
+        return dict(total_pairs=int(pairs_done), seconds=float(seconds), checksum=int(checksum),
+                    per_rank=[(int(pairs_done), float(seconds), int(checksum))])
     import torch
     import torch.distributed as dist
-    mine = torch.tensor([float(pairs_done), float(seconds)], dtype=torch.float64, device=device)
+    # the checksum travels as two 31-bit halves so that float64 carries it exactly
+    cs = int(checksum)
+    mine = torch.tensor([float(pairs_done), float(seconds), float(cs & 0x7fffffff), float((cs >> 31) & 0x7fffffff)],
+                        dtype=torch.float64, device=device)
     allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(allv, mine)
-    return sum(float(v[0]) for v in allv), max(float(v[1]) for v in allv)
+    rows = [(int(v[0].item()), float(v[1].item()), int(v[2].item()) | (int(v[3].item()) << 31)) for v in allv]
+    return dict(total_pairs=sum(r[0] for r in rows), seconds=max(r[1] for r in rows),
+                checksum=sum(r[2] for r in rows), per_rank=rows)
+
+
+def gather_throughput(pairs_done, seconds, device):
+    """all_gather of per-rank (pairs, seconds); returns (total_pairs, max_seconds)."""
+    r = aggregate(pairs_done, seconds, 0, device, distributed=True)
+    return float(r["total_pairs"]), r["seconds"]
+
+
+def ranks_agree(value, device):
+    """True on every rank iff all ranks hold the same int64 ``value`` (MIN == MAX all-reduce)."""
+    import torch
+    import torch.distributed as dist
+    v = int(value)
+    t = torch.tensor([v & 0x7fffffff, (v >> 31) & 0x7fffffff, -(v & 0x7fffffff), -((v >> 31) & 0x7fffffff)],
+                     dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t[0].item()) == -int(t[2].item()) and int(t[1].item()) == -int(t[3].item())

@@ -1,9 +1,11 @@
 """``Stereo`` -- the stereo pipeline object of the reference with its per-pair work on the MI355X.
 
-Mirrors /root/reference/calibrating/stereo_camera.py for the depth path:
-  load / dump / copy                  :244-302
-  _get_undistort_rectify_map          :125-185   (init time, host NumPy)
-  stereo_recitfy                      :199-214   (init time, host NumPy; spelling is the reference's)
+Public names and semantics follow /root/reference/calibrating/stereo_camera.py for the depth path;
+the bodies are this package's own: rig geometry lives in ``geometry.py`` as pure functions
+(``rectifying_rotations``, ``target_intrinsics``), the per-pair stages call the gfx950 kernels.
+  load / dump / copy                  :244-302   record = {R | T | r, t, cam1, cam2[, retval]}
+  _get_undistort_rectify_map          :125-185   (init time; maps built lazily, on the GPU)
+  stereo_recitfy                      :199-214   (spelling is the reference's)
   rectify                             :216-242   -> imgproc.remap (Lanczos-4 kernel, x-shift fused)
   set_stereo_matching                 :466-489
   get_depth                           :492-533   -> kernels, every intermediate stays in HBM
@@ -17,107 +19,77 @@ NumPy in -> NumPy out (one H2D copy of the pair, one D2H copy per result entry);
 in -> torch tensors out, zero-copy.
 """
 import numpy as np
-import yaml
 
 from . import geometry, imgproc
-from .__info__ import __version__
-from .camera import Cam
+from .camera import Cam, read_record, write_record
 from .stereo_matching import SemiGlobalBlockMatching
 
-
-def _npa(v):
-    return np.array(v)
+_TABLE_KEYS = ("map1x", "map1y", "map2x", "map2y", "mask")
 
 
 class Stereo:
+    DUMP_ATTRS = ["R", "t", "retval"]
+    MAX_DEPTH = 1000
+
     def __init__(self, cam1=None, cam2=None, xy_target=None, K_target=1, R=None, t=None):
         """K_target: float or np.array(3, 3): the new camera intrinsic; a float multiplies fx, fy."""
         self.xy_target = xy_target
         self.K_target = K_target
         if cam1 is None:
             return
-        self.cam1 = cam1
-        self.cam2 = cam2
         if R is None or t is None:
             raise NotImplementedError(
                 "extrinsic calibration from board detections (cv2.stereoCalibrate) is outside the MI355X "
                 "stereo-depth path; pass R= and t=, or use Stereo.load(dict(R=..., t=..., cam1=..., cam2=...))")
-        self.R = np.float64(R)
-        self.t = np.float64(t).reshape(3, 1)
+        self.cam1, self.cam2 = cam1, cam2
+        self._set_pose(R, t)
         self._get_undistort_rectify_map()
 
-    # ---- init-time tables (host) -----------------------------------------------------------------
+    def _set_pose(self, R, t):
+        self.R = np.float64(R)
+        self.t = np.float64(t).reshape(3, 1)
+
+    # ---- init-time geometry (host, 3x3 algebra only) -----------------------------------------------
+    def stereo_recitfy(self):
+        self.R1, self.R2 = geometry.rectifying_rotations(self.R, self.t)
+
     def _get_undistort_rectify_map(self):
         self.stereo_recitfy()
-        if self.xy_target is None:
+        self.xy, self.K = geometry.target_intrinsics(self.cam1.K, self.cam1.xy, self.cam2.K, self.cam2.xy,
+                                                     self.R1, self.R2, self.xy_target, self.K_target)
+        if self.xy_target is None:  # the attribute ends up resolved, as in the reference
             self.xy_target = self.cam1.xy
-        if isinstance(self.xy_target, (int, float)):
-            self.xy_target = [int(round(i * self.xy_target)) for i in self.cam1.xy]
-        self.xy = xy = tuple(self.xy_target)
-        self.K = self.K_target
-        if isinstance(self.K_target, (int, float)):
-            self.K = self.cam1.K.copy()
-            self.K[:2, :2] *= self.K_target
-            self.K[:2, 2] += (np.array(xy) - self.cam1.xy) / 2
-        if not isinstance(self.K_target, np.ndarray):  # "better_cx_cy"
+        elif isinstance(self.xy_target, (int, float)):
+            self.xy_target = list(self.xy)
+        # The four maps + valid mask are built on the GPU when a stage first needs them (_tables); the host
+        # copies (undistort_rectify_map1/2, rectify_valid_mask1: public attributes in the reference) are lazy.
+        self._host, self._dev = {}, {}
 
-            def get_center(xy, K, R):
-                corner_uvs_real = [[0, 0, 1], [xy[0], 0, 1], list(xy) + [1], [0, xy[1], 1]]
-                corner_xyz_old = np.array(corner_uvs_real) @ np.linalg.inv(K).T
-                corner_xyz = corner_xyz_old @ R.T
-                corner_uvs = corner_xyz @ self.K.T
-                corner_uvs = corner_uvs[:, :2] / corner_uvs[:, 2:]
-                center_uv = corner_uvs.mean(0)
-                return center_uv - self.K[:2, 2]
+    def _host_table(self, name, build):
+        if name not in self._host:
+            self._host[name] = build()
+        return self._host[name]
 
-            center1 = get_center(self.cam1.xy, self.cam1.K, self.R1)
-            center2 = get_center(self.cam2.xy, self.cam2.K, self.R2)
-            center = (center1 + center2) / 2
-            self.K[:2, 2] = np.array(xy) / 2 - center
-
-        # The maps themselves are built on the GPU when a stage first needs them (_tables); the host copies
-        # (undistort_rectify_map1/2, rectify_valid_mask1: public attributes in the reference) are lazy.
-        for k in ("_map1", "_map2", "_mask1", "_unrectify_depth_maps"):
-            self.__dict__.pop(k, None)
-        self._dev = {}  # device tables, built lazily per device
-
-    # host views of the tables, computed on first access (NumPy, float64 internally)
     @property
     def undistort_rectify_map1(self):
-        if "_map1" not in self.__dict__:
-            self._map1 = geometry.init_undistort_rectify_map(self.cam1.K, self.cam1.D, self.R1, self.K, self.xy)
-        return self._map1
+        return self._host_table("map1", lambda: geometry.init_undistort_rectify_map(
+            self.cam1.K, self.cam1.D, self.R1, self.K, self.xy))
 
     @property
     def undistort_rectify_map2(self):
-        if "_map2" not in self.__dict__:
-            self._map2 = geometry.init_undistort_rectify_map(self.cam2.K, self.cam2.D, self.R2, self.K, self.xy)
-        return self._map2
+        return self._host_table("map2", lambda: geometry.init_undistort_rectify_map(
+            self.cam2.K, self.cam2.D, self.R2, self.K, self.xy))
 
     @property
     def rectify_valid_mask1(self):
-        if "_mask1" not in self.__dict__:
-            mapx, mapy = self.undistort_rectify_map1
-            x, y = self.cam1.xy
-            self._mask1 = (-0.5 < mapx) & (mapx < x - 0.5) & (-0.5 < mapy) & (mapy < y - 0.5)
-        return self._mask1
+        return self._host_table("mask1", lambda: geometry.valid_mask_from_maps(
+            *self.undistort_rectify_map1, self.cam1.xy))
 
-    def stereo_recitfy(self):
-        axes_z = np.array([0, 0, 1.0])
-        axes_nx = np.array([-1.0, 0, 0])
-        t = self.t.squeeze()
-        plane_v = t
-        z_on_plane2 = geometry.project_vec_on_plane(axes_z, plane_v)
-        z_on_plane1 = geometry.project_vec_on_plane(self.R @ axes_z, plane_v)
-        z_on_plane = z_on_plane2 / np.linalg.norm(z_on_plane2) + z_on_plane1 / np.linalg.norm(z_on_plane1)
-        R_align_x = geometry.rotate_shortest_of_two_vecs(axes_nx, t)
-        R_align_z = geometry.rotate_shortest_of_two_vecs(R_align_x @ axes_z, z_on_plane)
-        self.R2 = (R_align_z @ R_align_x).T
-        self.R1 = self.R2 @ self.R[:3, :3]
-
+    # ---- device tables -----------------------------------------------------------------------------
     def _tables(self, device):
         """Device-resident tables of this rig: {map1x, map1y, map2x, map2y, mask}, built by the GPU kernel
-        (camd_init_undistort_rectify_map; bit-identical to the host properties above)."""
+        (camd_init_undistort_rectify_map; bit-identical to the host properties above) unless a broadcast
+        bundle was installed for ``device`` (install_tables)."""
         key = str(device)
         if key not in self._dev:
             m1x, m1y, mask = imgproc.init_undistort_rectify_map(
@@ -128,16 +100,111 @@ class Stereo:
         return self._dev[key]
 
     def table_bundle(self):
-        """Host copies of everything a worker rank needs (bench.py broadcasts this over RCCL)."""
-        return dict(map1x=self.undistort_rectify_map1[0], map1y=self.undistort_rectify_map1[1],
-                    map2x=self.undistort_rectify_map2[0], map2y=self.undistort_rectify_map2[1],
-                    mask=self.rectify_valid_mask1.view(np.uint8))
+        """Host copies of everything a worker rank needs (parallel_pairs.broadcast_tables sends this)."""
+        (m1x, m1y), (m2x, m2y) = self.undistort_rectify_map1, self.undistort_rectify_map2
+        return dict(map1x=m1x, map1y=m1y, map2x=m2x, map2y=m2y, mask=self.rectify_valid_mask1.view(np.uint8))
+
+    def install_tables(self, bundle, device=None):
+        """Use the tensors of a broadcast table bundle (parallel_pairs.broadcast_tables) as this rig's device
+        tables on ``device`` instead of rebuilding them: the worker-rank side of the one-time RCCL broadcast."""
+        missing = [k for k in _TABLE_KEYS if k not in bundle]
+        if missing:
+            raise ValueError("table bundle lacks %s" % missing)
+        h, w = bundle["map1x"].shape
+        if (w, h) != tuple(self.xy):
+            raise ValueError("bundle is for a %dx%d rectified image, this rig rectifies to %dx%d" % (w, h, *self.xy))
+        device = bundle["map1x"].device if device is None else device
+        self._dev[str(device)] = {k: bundle[k] for k in _TABLE_KEYS}
+        return self
+
+    # ---- record I/O --------------------------------------------------------------------------------
+    def dump(self, path="", return_dict=False):
+        rec = {k: (v.tolist() if isinstance(v, np.ndarray) else v)
+               for k, v in vars(self).items() if k in self.DUMP_ATTRS}
+        rec.update(cam1=self.cam1.dump(return_dict=True), cam2=self.cam2.dump(return_dict=True))
+        return rec if return_dict else write_record(rec, path)
+
+    def load(self, path_or_str_or_dict=None):
+        """``Stereo.load(record)`` (on the class: new object) or ``stereo.load(record)`` (in place; xy_target /
+        K_target of the object are kept).  record: dict, YAML text or YAML file path."""
+        if path_or_str_or_dict is None:  # Stereo.load(x) binds x to `self`
+            return Stereo().load(self)
+        if isinstance(path_or_str_or_dict, Stereo):
+            return path_or_str_or_dict.copy()
+        rec = read_record(path_or_str_or_dict) if not isinstance(path_or_str_or_dict, dict) \
+            else dict(path_or_str_or_dict)
+        rec.pop("_calibrating_version", None)
+        for name in ("cam1", "cam2"):
+            if hasattr(self, name):
+                getattr(self, name).load(rec.pop(name))
+            else:
+                setattr(self, name, Cam.load(rec.pop(name)))
+        geometry.rig_rotation_from_record(rec)
+        for k, v in rec.items():
+            setattr(self, k, np.array(v) if k in self.DUMP_ATTRS else v)
+        self._set_pose(self.R, self.t)
+        self._get_undistort_rectify_map()
+        return self
+
+    def copy(self):
+        return type(self)().load(self.dump())
+
+    def __str__(self):
+        rvec = geometry.rodrigues(self.R).reshape(3)
+        lines = ["Stereo(cam1='%s', cam2='%s'):" % (self.cam1.name, self.cam2.name),
+                 "\t xy: %s" % ", ".join(str(v) for v in self.cam1.xy),
+                 "\t baseline: %.2fcm" % (100 * self.baseline),
+                 "\t t(cm): [%s]" % " ".join(str(v) for v in (self.t.reshape(3) * 100).round(2)),
+                 "\t r(rodrigues): [%s] %.2f\u00b0" % (" ".join(str(v) for v in rvec.round(3)),
+                                                    np.degrees(np.linalg.norm(rvec)))]
+        if hasattr(self, "retval"):
+            lines.append("\t retval: %s" % self.retval)
+        return "\n".join(lines) + "\n"
+
+    __repr__ = __str__
+
+    # ---- small properties (names of the reference, :386-406) ----------------------------------------
+    def get_max_depth(self):
+        return getattr(self, "max_depth", self.MAX_DEPTH)
+
+    @property
+    def D(self):
+        return np.zeros((1, 5))  # the rectified camera has no distortion
+
+    @property
+    def T(self):
+        return geometry.R_t_to_T(self.R, self.t)
+
+    @property
+    def baseline(self):
+        return float(np.sqrt(np.sum(np.square(self.t))))
+
+    def depth_to_disparity(self, depth):
+        return 1.0 * self.baseline * self.K[0, 0] / depth
+
+    def disparity_to_depth(self, disparity):
+        """NumPy or torch ``disparity`` -> depth, same dtype rules and edge cases as :408-413: inf (d = 0)
+        and everything beyond max_depth become 0, then negatives become 0."""
+        bf = 1.0 * self.baseline * self.K[0, 0]
+        if isinstance(disparity, np.ndarray):
+            with np.errstate(divide="ignore"):
+                depth = bf / disparity
+        else:
+            import torch
+            depth = float(bf) / disparity.to(torch.float64)
+        depth[depth > self.get_max_depth()] = 0
+        depth[depth < 0] = 0
+        return depth
 
     # ---- per-pair stages ---------------------------------------------------------------------------
     @staticmethod
     def _get_img(path_or_np):
+        """A file path is read as RGB uint8 (the reference: ``cv2.imread(path)[..., ::-1]``, :304-308; here
+        through Pillow, which decodes PNG/BMP/PPM to the same bytes -- JPEG decoders may differ by 1 LSB)."""
         if isinstance(path_or_np, str):
-            raise NotImplementedError("image files are read by the caller on this path (no cv2.imread)")
+            from PIL import Image
+            with Image.open(path_or_np) as im:
+                return np.asarray(im.convert("RGB"))
         return path_or_np
 
     @staticmethod
@@ -158,111 +225,6 @@ class Stereo:
             return [rectify_img1.cpu().numpy(), rectify_img2.cpu().numpy()]
         return [rectify_img1, rectify_img2]
 
-    DUMP_ATTRS = ["R", "t", "retval"]
-
-    def dump(self, path="", return_dict=False):
-        dic = {k: v.tolist() if isinstance(v, np.ndarray) else v
-               for k, v in self.__dict__.items() if k in self.DUMP_ATTRS}
-        dic["cam1"] = self.cam1.dump(return_dict=True)
-        dic["cam2"] = self.cam2.dump(return_dict=True)
-        if return_dict:
-            return dic
-        dic["_calibrating_version"] = __version__
-        yamlstr = yaml.safe_dump(dic)
-        if path:
-            with open(path, "w") as f:
-                f.write(yamlstr)
-        return yamlstr
-
-    def load(self, path_or_str_or_dict=None):
-        if path_or_str_or_dict is None:
-            path_or_str_or_dict = self
-            self = Stereo()
-        if isinstance(path_or_str_or_dict, Stereo):
-            return path_or_str_or_dict.copy()
-        if not isinstance(path_or_str_or_dict, (list, dict)):
-            path_or_str = path_or_str_or_dict
-            if "\n" in path_or_str:
-                dic = yaml.safe_load(path_or_str)
-            else:
-                with open(path_or_str) as f:
-                    dic = yaml.safe_load(f)
-        else:
-            dic = dict(path_or_str_or_dict)
-        dic.pop("_calibrating_version", None)
-        if hasattr(self, "cam1"):
-            self.cam1.load(dic.pop("cam1"))
-            self.cam2.load(dic.pop("cam2"))
-        else:
-            self.cam1 = Cam.load(dic.pop("cam1"))
-            self.cam2 = Cam.load(dic.pop("cam2"))
-        if "R" not in dic and "T" in dic:
-            dic["r"], dic["t"] = geometry.T_to_r_t(np.asarray(dic.pop("T"), np.float64))
-        if "R" not in dic and "r" in dic:
-            dic["R"] = geometry.rodrigues(np.asarray(dic.pop("r"), np.float64).reshape(3))
-        dic.setdefault("R", np.eye(3))
-        self.__dict__.update({k: _npa(v) if k in self.DUMP_ATTRS else v for k, v in dic.items()})
-        self.R = np.float64(self.R)
-        self.t = np.float64(self.t).reshape(3, 1)
-        self._get_undistort_rectify_map()
-        return self
-
-    def copy(self):
-        new = type(self)()
-        new.load(self.dump())
-        return new
-
-    def __str__(self):
-        r = geometry.rodrigues(self.R).squeeze()
-        du = np.linalg.norm(r) * 180 / np.pi
-        strr = "Stereo(cam1='%s', cam2='%s'):\n" % (self.cam1.name, self.cam2.name)
-        strr += "\t xy: %s\n" % str(list(self.cam1.xy))[1:-1]
-        strr += "\t baseline: %.2fcm\n" % (100 * self.baseline)
-        strr += "\t t(cm): [%s]\n" % (" ".join([str(i) for i in (self.t.squeeze() * 100).round(2)]))
-        strr += "\t r(rodrigues): [%s] %.2f deg\n" % (" ".join([str(i) for i in r.round(3)]), du)
-        if hasattr(self, "retval"):
-            strr += "\t retval: %s\n" % self.retval
-        return strr
-
-    __repr__ = __str__
-
-    MAX_DEPTH = 1000
-
-    def get_max_depth(self):
-        return getattr(self, "max_depth", self.MAX_DEPTH)
-
-    @property
-    def D(self):
-        return np.zeros((1, 5))
-
-    @property
-    def T(self):
-        return geometry.R_t_to_T(self.R, self.t)
-
-    @property
-    def baseline(self):
-        return np.sum(self.t ** 2) ** 0.5
-
-    def depth_to_disparity(self, depth):
-        fx = self.K[0, 0]
-        return 1.0 * self.baseline * fx / depth
-
-    def disparity_to_depth(self, disparity):
-        """NumPy or torch ``disparity`` -> depth, same dtype rules and edge cases as :408-413."""
-        fx = self.K[0, 0]
-        bf = 1.0 * self.baseline * fx
-        if isinstance(disparity, np.ndarray):
-            with np.errstate(divide="ignore"):
-                depth = bf / disparity
-            depth[depth > self.get_max_depth()] = 0
-            depth[depth < 0] = 0
-            return depth
-        import torch
-        depth = float(bf) / disparity.to(torch.float64)
-        depth[depth > self.get_max_depth()] = 0
-        depth[depth < 0] = 0
-        return depth
-
     def _unrectify_tables(self, device):
         # utils.py:183-191: initUndistortRectifyMap(K, None, R1.T, cam1.K, cam1.xy), memoised per device
         key = "unrect:" + str(device)
@@ -279,7 +241,7 @@ class Stereo:
         return out.cpu().numpy() if was_np else out
 
     def undistort_img(self, img1):
-        i1, was_np = self._to_dev(img1)
+        i1, was_np = self._to_dev(self._get_img(img1))
         key = "undist:" + str(i1.device)
         if key not in self._dev:
             self._dev[key] = imgproc.undistort_maps_device(self.cam1.K, self.cam1.D, self.cam1.xy, device=i1.device)
@@ -292,19 +254,44 @@ class Stereo:
                                   "stereo_camera.py:433-464) is outside the MI355X hot path")
 
     def set_stereo_matching(self, stereo_matching, max_depth=None, translation_rectify_img=None):
-        """Same semantics as :466-489 (note: min_disparity uses cam1.K, disparity_to_depth self.K)."""
+        """Install the matcher plugin (:466-489).  ``max_depth`` (default MAX_DEPTH) fixes
+        ``min_disparity = int(cam1.fx * baseline / max_depth)`` -- note cam1's fx here, the rectified K in
+        disparity_to_depth; ``translation_rectify_img`` defaults to ``bool(max_depth)``."""
         self.stereo_matching = stereo_matching
-        self.translation_rectify_img = (bool(max_depth) if translation_rectify_img is None
-                                        else translation_rectify_img)
+        self.translation_rectify_img = bool(max_depth) if translation_rectify_img is None \
+            else translation_rectify_img
         self.max_depth = max_depth or self.MAX_DEPTH
         self.min_disparity = int(self.cam1.K[0, 0] * self.baseline / self.max_depth)
         return self
+
+    def _sgbm_full_res(self, rectified_hw):
+        """The SGBM plugin when it runs at the rectified resolution (no max_size downsizing), else None."""
+        sm = self.stereo_matching
+        if isinstance(sm, SemiGlobalBlockMatching) and min(sm.max_size / max(rectified_hw), 1) == 1:
+            return sm
+        return None
+
+    def _fused_depth(self, sm, disp16, tables):
+        # matcher post-processing, += min_disparity, * mask and disparity_to_depth in one kernel
+        return imgproc.disp_to_depth(disp16, tables["mask"], sm.stereo_sgbm.getMinDisparity(), self.min_disparity,
+                                     bool(self.translation_rectify_img), 1.0 * self.baseline * self.K[0, 0],
+                                     self.get_max_depth())
+
+    def _finish(self, result, i1, was_np, return_unrectify_depth, sgbm=None):
+        import torch
+        if return_unrectify_depth:
+            result.update(unrectify_depth=self.unrectify_depth(result["rectify_depth"]),
+                          undistort_img1=self.undistort_img(i1))
+        if was_np:
+            result = {k: v.cpu().numpy() if isinstance(v, torch.Tensor) else v for k, v in result.items()}
+            if sgbm is not None:
+                sgbm.status()  # the D2H copies above synchronised: surface device-side timeouts at no extra cost
+        return result
 
     def get_depth(self, img1, img2, return_unrectify_depth=True, return_distort_depth=False):
         """Return dict: rectify_img1, rectify_depth, disparity, rectify_img2 (+ unrectify_depth,
         undistort_img1). Depth unit is m; 0 = invalid."""
         import torch
-        result = {}
         assert hasattr(self, "stereo_matching"), "Please stereo.set_stereo_matching(stereo_matching)"
         if return_distort_depth:
             self.distort_depth(None)
@@ -312,39 +299,31 @@ class Stereo:
         i2, _ = self._to_dev(self._get_img(img2))
         rectify_img1, rectify_img2 = self.rectify(i1, i2)
         tb = self._tables(i1.device)
-        sm = self.stereo_matching
-        translate = bool(getattr(self, "translation_rectify_img"))
-        fused = isinstance(sm, SemiGlobalBlockMatching) and \
-            min(sm.max_size / max(rectify_img1.shape[:2]), 1) == 1
-        if fused:
-            # matcher post-processing, += min_disparity, * mask and disparity_to_depth in one kernel
+        result = {}
+        sm = self._sgbm_full_res(rectify_img1.shape[:2])
+        if sm is not None:
             disp16, _ = sm.compute_disp16(rectify_img1, rectify_img2)
-            disparity, rectify_depth = imgproc.disp_to_depth(
-                disp16, tb["mask"], sm.stereo_sgbm.getMinDisparity(), self.min_disparity, translate,
-                1.0 * self.baseline * self.K[0, 0], self.get_max_depth())
+            disparity, rectify_depth = self._fused_depth(sm, disp16, tb)
         else:
-            if isinstance(sm, SemiGlobalBlockMatching):
-                disparity = sm(rectify_img1, rectify_img2)
-            else:  # foreign plugin: reference contract is NumPy in / NumPy (or dict) out
-                disparity = sm(rectify_img1.cpu().numpy(), rectify_img2.cpu().numpy())
+            plugin = self.stereo_matching
+            if isinstance(plugin, SemiGlobalBlockMatching):  # downsizing SGBM: stays on the GPU
+                disparity = plugin(rectify_img1, rectify_img2)
+            else:  # foreign plugin: the reference's contract is NumPy in, NumPy (or dict) out
+                disparity = plugin(rectify_img1.cpu().numpy(), rectify_img2.cpu().numpy())
             if isinstance(disparity, dict):
                 result.update(disparity)
                 disparity = disparity["disparity"]
+            if self.translation_rectify_img:
+                disparity += self.min_disparity  # in place, on the plugin's own array like :510-511
             if isinstance(disparity, np.ndarray):
                 disparity = torch.from_numpy(np.ascontiguousarray(disparity)).to(i1.device)
-            if translate:
-                disparity += self.min_disparity
             disparity = tb["mask"].to(torch.bool) * disparity
             rectify_depth = self.disparity_to_depth(disparity)
-
         result.update(rectify_img1=rectify_img1, rectify_depth=rectify_depth, disparity=disparity,
                       rectify_img2=rectify_img2)
-        if return_unrectify_depth:
-            result.update(unrectify_depth=self.unrectify_depth(rectify_depth),
-                          undistort_img1=self.undistort_img(i1))
-        if was_np:
-            result = {k: v.cpu().numpy() if isinstance(v, torch.Tensor) else v for k, v in result.items()}
-        return result
+        plugin = self.stereo_matching
+        return self._finish(result, i1, was_np, return_unrectify_depth,
+                            plugin.stereo_sgbm if isinstance(plugin, SemiGlobalBlockMatching) else None)
 
     def get_depth_batch(self, imgs1, imgs2, return_unrectify_depth=True):
         """``get_depth`` for ``n`` pairs of the same rig at once: ``imgs1`` / ``imgs2`` are ``(n, h, w, 3)``
@@ -353,27 +332,23 @@ class Stereo:
         Not in the reference (its ``get_depth`` takes one pair, stereo_camera.py:491-533); this is the
         throughput form of the same stages -- each kernel is launched once for the whole batch, which is
         what keeps small images (VGA) from being launch-bound.  Pair ``i`` of the result is bit-identical
-        to ``get_depth(imgs1[i], imgs2[i])``.  Requires the SGBM plugin without downsizing.
+        to ``get_depth(imgs1[i], imgs2[i])``.  Requires the SGBM plugin with ``max_size`` >= the RECTIFIED
+        image size (the size the matcher sees, as in get_depth).
         """
-        import torch
         assert hasattr(self, "stereo_matching"), "Please stereo.set_stereo_matching(stereo_matching)"
         i1, was_np = self._to_dev(imgs1)
         i2, _ = self._to_dev(imgs2)
         if i1.dim() != 4 or i1.shape != i2.shape:
             raise ValueError("imgs1 / imgs2 must be (n, h, w, c) arrays of equal shape")
-        sm = self.stereo_matching
-        if not (isinstance(sm, SemiGlobalBlockMatching) and min(sm.max_size / max(i1.shape[1:3]), 1) == 1):
-            raise ValueError("get_depth_batch needs a SemiGlobalBlockMatching plugin with max_size >= image size")
+        if not isinstance(self.stereo_matching, SemiGlobalBlockMatching):
+            raise ValueError("get_depth_batch needs a SemiGlobalBlockMatching plugin")
         rectify_img1, rectify_img2 = self.rectify(i1, i2)
+        sm = self._sgbm_full_res(rectify_img1.shape[1:3])
+        if sm is None:
+            raise ValueError("get_depth_batch needs max_size >= the rectified image size %s (got max_size=%s)"
+                             % (tuple(rectify_img1.shape[1:3]), self.stereo_matching.max_size))
         tb = self._tables(i1.device)
-        disp16 = sm.stereo_sgbm.compute(rectify_img1, rectify_img2)
-        disparity, rectify_depth = imgproc.disp_to_depth(
-            disp16, tb["mask"], sm.stereo_sgbm.getMinDisparity(), self.min_disparity,
-            bool(getattr(self, "translation_rectify_img")), 1.0 * self.baseline * self.K[0, 0], self.get_max_depth())
+        disparity, rectify_depth = self._fused_depth(sm, sm.stereo_sgbm.compute(rectify_img1, rectify_img2), tb)
         result = dict(rectify_img1=rectify_img1, rectify_depth=rectify_depth, disparity=disparity,
                       rectify_img2=rectify_img2)
-        if return_unrectify_depth:
-            result.update(unrectify_depth=self.unrectify_depth(rectify_depth), undistort_img1=self.undistort_img(i1))
-        if was_np:
-            result = {k: v.cpu().numpy() if isinstance(v, torch.Tensor) else v for k, v in result.items()}
-        return result
+        return self._finish(result, i1, was_np, return_unrectify_depth, sm.stereo_sgbm)

@@ -83,10 +83,17 @@ int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* st
  *   CAMD_PATH_BAND            fused band-wavefront passes (throughput; D in (32, 256])
  *   CAMD_PATH_CONCURRENT      all directions at once into per-direction volumes (latency; <= 8 pairs per call)
  * CAMD_OPT_KEEP_S 1 = the band path also stores the final S volume (for camd_sgbm_debug_copy(which = 1)). */
-enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1 };
+enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1, CAMD_OPT_COST = 2 };
 enum { CAMD_PATH_AUTO = 0, CAMD_PATH_SCAN = 1, CAMD_PATH_BAND = 2, CAMD_PATH_CONCURRENT = 3 };
+/* CAMD_OPT_COST selects how the matching-cost volume C is built (bit-identical results):
+ *   CAMD_COST_AUTO (default)  the fused kernel where it is instantiated (blockSize <= 11), else the split pair
+ *   CAMD_COST_FUSED           k_cost: BT pixel cost + blockSize x blockSize box sum + P2 -> C, written once
+ *   CAMD_COST_SPLIT           k_hsum (BT + horizontal sum) -> intermediate volume -> k_vsum (vertical sum) -> C */
+enum { CAMD_COST_AUTO = 0, CAMD_COST_FUSED = 1, CAMD_COST_SPLIT = 2 };
 int camd_sgbm_set_option(camd_sgbm* h, int option, int value);
-/* synchronises `stream` and reports whether a device-side bounded wait of the last computes timed out */
+/* synchronises `stream` and reports whether a device-side bounded wait of the last computes timed out.
+ * Without this call a timeout still cannot pass unnoticed: the affected call's disparities are written as
+ * all-invalid ((minDisparity - 1) * 16), and the next camd_sgbm_compute on the handle returns CAMD_ERR_HIP. */
 int camd_sgbm_status(camd_sgbm* h, void* stream);
 /* per-stage GPU time of the last compute, measured with hipEvents on `stream` (enable first).
  * stage names: camd_sgbm_stage_name(i), i in [0, camd_sgbm_num_stages()) */

@@ -24,16 +24,28 @@ def _worker(rank, world, port, q):
     try:
         import calibrating_amd as ca
         from calibrating_amd import synthetic
-        from calibrating_amd.parallel_pairs import broadcast_tables, gather_throughput, shard_range
+        from calibrating_amd.parallel_pairs import (aggregate, broadcast_tables, gather_throughput, ranks_agree,
+                                                    shard_range, timed_steps)
         bundle = None
         if rank == 0:
             bundle = ca.Stereo.load(synthetic.rig(160, 120)).table_bundle()
         tabs = broadcast_tables(bundle, torch.device("cpu"), src=0)
         ref = ca.Stereo.load(synthetic.rig(160, 120)).table_bundle()  # every rank can rebuild it to compare
         ok = all(np.array_equal(tabs[k].numpy(), ref[k]) for k in ref)
+        # worker-rank side of the broadcast: the bundle becomes the rig's device tables without a rebuild
+        st = ca.Stereo.load(synthetic.rig(160, 120)).install_tables(tabs, torch.device("cpu"))
+        ok = ok and st._tables(torch.device("cpu"))["map2y"] is tabs["map2y"]
         lo, hi = shard_range(11, world, rank)
         total, tmax = gather_throughput(hi - lo, 1.0 + rank, torch.device("cpu"))
-        q.put((rank, ok, lo, hi, total, tmax))
+        # the code path bench.py times and aggregates with (same functions, gloo instead of RCCL)
+        calls = []
+        dt = timed_steps(lambda: calls.append(1), steps=3, warmup=2, synchronize=None, distributed=True)
+        big = (1 << 40) + 12345 + rank  # a checksum beyond float32 / int32 range must survive the reduction
+        agg = aggregate(hi - lo, dt, big, torch.device("cpu"), distributed=True)
+        same = ranks_agree(777, torch.device("cpu"))
+        diff = ranks_agree(777 + rank, torch.device("cpu"))
+        q.put((rank, ok, lo, hi, total, tmax, len(calls), agg["total_pairs"], agg["checksum"], agg["seconds"] >= dt,
+               same, diff))
     finally:
         dist.destroy_process_group()
 
@@ -53,3 +65,21 @@ def test_table_broadcast_and_sharding_world2():
     assert all(r[1] for r in res), "broadcast tables differ from the source"
     assert (res[0][2], res[0][3], res[1][2], res[1][3]) == (0, 6, 6, 11)
     assert res[0][4] == 11 and res[0][5] == 2.0
+    for r in res:
+        assert r[6] == 5                                   # 2 warm-up + 3 timed calls
+        assert r[7] == 11                                  # pairs over both ranks
+        assert r[8] == 2 * ((1 << 40) + 12345) + 1         # checksum of checksums, exact
+        assert r[9] and r[10] and not r[11]                # MAX of seconds; agreement detector both ways
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`bench.py --gpus 2` without that many GPUs must exit non-zero with a message, not report n_gpus=1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert p.returncode != 0
+    assert "GPU(s) visible" in p.stderr
+    assert not p.stdout.strip()
