@@ -67,6 +67,12 @@ __device__ __forceinline__ uint32_t pk_addsat_i16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2_t, a),
                                                                       __builtin_bit_cast(s16x2_t, b)));
 }
+// signed saturating subtract
+__device__ __forceinline__ uint32_t pk_subsat_i16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, a),
+                                                                      __builtin_bit_cast(s16x2_t, b)));
+}
 // a * b + c per half, saturated to 0xFFFF (v_pk_mad_u16 ... clamp)
 __device__ __forceinline__ uint32_t pk_mad_sat_u16(uint32_t a, uint32_t b, uint32_t c)
 {

@@ -224,26 +224,34 @@ __global__ __launch_bounds__(512) void k_hsum(const uint8_t* __restrict__ left,
 // ------------------------------------------------------------------------------------------------
 static constexpr int VSUM_ROWS = 64;
 
+// SAT: the saturating recurrence of OpenCV's CV_SIMD build (see sgbm_cost.hpp); then one block walks ALL rows.
+template <bool SAT>
 __global__ __launch_bounds__(256) void k_vsum(const uint4* __restrict__ Hs, uint4* __restrict__ C, Geom g,
-                                              size_t vol_stride16)
+                                              size_t vol_stride16, int rows_per_block)
 {
     extern __shared__ uint4 vring[];  // [K][256]
     const size_t rowv = (size_t)g.W1 * (g.Dp / 8);  // uint4 per row
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool ok = i0 < rowv;
     const size_t i = ok ? i0 : rowv - 1;
+    const bool first_col = i < (size_t)(g.Dp / 8);  // cost column 0
     const int pair = blockIdx.z, H = g.H, SH2 = g.SW2, K = 2 * SH2 + 1;
-    const int y0 = blockIdx.y * VSUM_ROWS, y1 = min(y0 + VSUM_ROWS, H);
+    const int y0 = blockIdx.y * rows_per_block, y1 = min(y0 + rows_per_block, H);
     const uint4* base = Hs + (size_t)pair * vol_stride16 + i;
     uint4* out = C + (size_t)pair * vol_stride16 + i;
     auto ld = [&](int yy) -> uint4 { return base[(size_t)min(max(yy, 0), H - 1) * rowv]; };
+    auto add = [&](uint32_t a, uint32_t b) { return SAT ? pk_addsat_i16(a, b) : pk_add_u16(a, b); };
+    auto upd = [&](uint32_t a, uint32_t v, uint32_t o, bool add_first) {
+        if (!SAT) return pk_sub_u16(pk_add_u16(a, v), o);
+        return add_first ? pk_subsat_i16(pk_addsat_i16(a, v), o) : pk_addsat_i16(pk_subsat_i16(a, o), v);
+    };
     const uint32_t p2 = dup16((uint32_t)g.P2);
     uint4 acc = make_uint4(p2, p2, p2, p2);
     for (int j = 0; j < K; j++) {
         uint4 v = ld(y0 - SH2 + j);
         vring[j * 256 + threadIdx.x] = v;
-        acc.x = pk_add_u16(acc.x, v.x); acc.y = pk_add_u16(acc.y, v.y);
-        acc.z = pk_add_u16(acc.z, v.z); acc.w = pk_add_u16(acc.w, v.w);
+        acc.x = add(acc.x, v.x); acc.y = add(acc.y, v.y);
+        acc.z = add(acc.z, v.z); acc.w = add(acc.w, v.w);
     }
     if (ok) out[(size_t)y0 * rowv] = acc;
     int slot = 0;  // ring position of the oldest row (y - SH2 - 1 of the next output row)
@@ -259,8 +267,9 @@ __global__ __launch_bounds__(256) void k_vsum(const uint4* __restrict__ Hs, uint
                 const uint4 o = vring[slot * 256 + threadIdx.x];
                 vring[slot * 256 + threadIdx.x] = v;
                 slot = slot + 1 == K ? 0 : slot + 1;
-                acc.x = pk_sub_u16(pk_add_u16(acc.x, v.x), o.x); acc.y = pk_sub_u16(pk_add_u16(acc.y, v.y), o.y);
-                acc.z = pk_sub_u16(pk_add_u16(acc.z, v.z), o.z); acc.w = pk_sub_u16(pk_add_u16(acc.w, v.w), o.w);
+                const bool af = first_col && y + u + SH2 < H;  // OpenCV's order in column 0 while the entering row exists
+                acc.x = upd(acc.x, v.x, o.x, af); acc.y = upd(acc.y, v.y, o.y, af);
+                acc.z = upd(acc.z, v.z, o.z, af); acc.w = upd(acc.w, v.w, o.w, af);
                 if (ok) out[(size_t)(y + u) * rowv] = acc;
             }
         }
@@ -585,6 +594,7 @@ __global__ void k_fill_s16(int16_t* p, size_t pitch_e, size_t stride_e, int W, i
 
 }  // namespace camd
 #include "sgbm_band.hpp"
+#include "sgbm_cost.hpp"
 namespace camd {
 
 // defined in post.hip
@@ -597,9 +607,10 @@ size_t speckle_ws_bytes(int w, int h, int batch);
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-enum Stage { ST_PREP = 0, ST_HSUM, ST_VSUM, ST_SCAN, ST_SCAN2, ST_WTA, ST_POST, ST_COUNT };
+enum Stage { ST_COST = 0, ST_HSUM, ST_VSUM, ST_SCAN, ST_SCAN2, ST_WTA, ST_POST, ST_COUNT };
+// "cost" = the fused cost kernel (then hsum / vsum are empty), "hsum" + "vsum" = the split pair (then cost is empty);
 // "scan" = the aggregation launches; on the band path the last pass is timed separately as "scan_last"
-static const char* kStageNames[ST_COUNT] = {"bt_prepare", "hsum", "vsum", "scan", "scan_last", "wta", "median_speckle"};
+static const char* kStageNames[ST_COUNT] = {"cost", "hsum", "vsum", "scan", "scan_last", "wta", "median_speckle"};
 
 }  // namespace camd
 
@@ -616,6 +627,7 @@ struct camd_sgbm {
     int path;             // 0 = band passes (default when band_ok), 1 = one k_scan per direction
     int keep_S;           // band path: also store S in the final pass (stage-wise parity hook)
     int cost_path;        // CAMD_COST_*
+    int saturate;         // U7: 1 = C saturates like OpenCV's CV_SIMD build (default), 0 = wraps like the scalar build
     int nbands, nchunks;
     size_t erec_stride;
     unsigned long long* E;
@@ -845,6 +857,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     // band-wavefront path: instantiated for 16 lanes x {1,2} vectors and 8 lanes x 1 vector
     h->band_ok = w1 > 0 && g.uniq <= 99 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
     h->path = 0;
+    h->saturate = 1;
     h->epoch = 0;
     if (h->band_ok) {
         const int R = BAND_THREADS / g.lanes;
@@ -903,6 +916,7 @@ int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
     if (option == CAMD_OPT_PATH && value >= CAMD_PATH_AUTO && value <= CAMD_PATH_CONCURRENT) h->path = value;
     else if (option == CAMD_OPT_KEEP_S) h->keep_S = value != 0;
     else if (option == CAMD_OPT_COST && value >= CAMD_COST_AUTO && value <= CAMD_COST_SPLIT) h->cost_path = value;
+    else if (option == CAMD_OPT_SATURATE) h->saturate = value != 0;
     else { set_error("unknown option %d / value %d", option, value); return CAMD_ERR_BAD_ARG; }
     return CAMD_OK;
 }
@@ -984,9 +998,48 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         return CAMD_OK;
     }
 
-    MARK(ST_PREP);  // (the BT plane preprocessing is fused into k_hsum's LDS staging)
+    // ---- matching cost volume C ------------------------------------------------------------------------------
+    const int K = 2 * g.SW2 + 1;
+    // U7: int16 overflow is possible at all only beyond this bound; below it SAT == wrap
+    const bool may_overflow = (long long)K * K * g.cn * (2 * g.ftzero + 63) + g.P2 > 32767;
+    const bool sat = h->saturate && may_overflow;
+    const bool fused = K <= 11 && h->cost_path != CAMD_COST_SPLIT;
+    MARK(ST_COST);
+    if (fused) {
+        const int nw = g.Dp / COST_DL < 16 ? g.Dp / COST_DL : 16;       // waves per workgroup
+        const int ndblk = div_up(g.Dp, nw * COST_DL);                   // disparity blocks of <= 128
+        const int nstrips = div_up(g.W1, 64 - (K - 1));
+        // row chunks: enough workgroups for ~32 rounds over the chip, but the saturating recurrence must start at row 0
+        int nchunks = 1;
+        if (!sat) {
+            nchunks = div_up(8192, (long long)nstrips * ndblk * batch);
+            const int maxc = g.H / 32 > 1 ? g.H / 32 : 1;
+            nchunks = nchunks < 1 ? 1 : (nchunks > maxc ? maxc : nchunks);
+        }
+        const int rb = div_up(g.H, nchunks);
+        nchunks = div_up(g.H, rb);
+        dim3 grid(nstrips, nchunks * ndblk, batch), block(64 * nw);
+        const size_t lds = cost_lds_bytes(g.cn, nw);
+#define CAMD_COST(CNN, KK, SS)                                                                                       \
+    hipLaunchKernelGGL((k_cost<CNN, KK, SS>), grid, block, lds, st, left, right, pitch, image_stride, h->C, g, rb, \
+                       nchunks, h->vol_elems)
+#define CAMD_COST_K(CNN)                                                                  \
+    switch (K) {                                                                          \
+        case 1: CAMD_COST(CNN, 1, false); break;                                          \
+        case 3: CAMD_COST(CNN, 3, false); break;                                          \
+        case 5: if (sat) CAMD_COST(CNN, 5, true); else CAMD_COST(CNN, 5, false); break;   \
+        case 7: if (sat) CAMD_COST(CNN, 7, true); else CAMD_COST(CNN, 7, false); break;   \
+        case 9: if (sat) CAMD_COST(CNN, 9, true); else CAMD_COST(CNN, 9, false); break;   \
+        default: if (sat) CAMD_COST(CNN, 11, true); else CAMD_COST(CNN, 11, false);       \
+    }
+        // (K <= 3 cannot overflow: 9 * 3 * 317 + 16000 < 32768)
+        if (g.cn == 1) { CAMD_COST_K(1) } else { CAMD_COST_K(3) }
+#undef CAMD_COST_K
+#undef CAMD_COST
+        CAMD_LAUNCH_CHECK();
+    }
     MARK(ST_HSUM);
-    {
+    if (!fused) {
         int nseg = div_up(g.W1, HSUM_SEG), ndblk = div_up(g.Dp, 64);
         dim3 grid(nseg, g.H, batch), block(64 * ndblk);
         const int es = g.cn == 1 ? 4 : 12;
@@ -1014,18 +1067,24 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     }
 
     MARK(ST_VSUM);
-    {
+    if (!fused) {
         size_t rowv = (size_t)g.W1 * (g.Dp / 8);
-        const dim3 vgrid(div_up((long long)rowv, 256), div_up(g.H, VSUM_ROWS), batch);
         const uint4* hs4 = reinterpret_cast<const uint4*>(h->S);
         uint4* c4 = reinterpret_cast<uint4*>(h->C);
-        switch (2 * g.SW2 + 1) {
+        const size_t ring_lds = (size_t)K * 256 * sizeof(uint4);
+        if (sat) {
+            // the saturating recurrence runs from row 0 down the whole column (LDS-ring kernel, any K)
+            const dim3 vgrid(div_up((long long)rowv, 256), 1, batch);
+            hipLaunchKernelGGL(k_vsum<true>, vgrid, dim3(256), ring_lds, st, hs4, c4, g, h->vol_elems / 8, g.H);
+        } else {
+            const dim3 vgrid(div_up((long long)rowv, 256), div_up(g.H, VSUM_ROWS), batch);
+            switch (K) {
 #define CAMD_VSUM(KK) case KK: hipLaunchKernelGGL((k_vsum_reg<KK>), vgrid, dim3(256), 0, st, hs4, c4, g, h->vol_elems / 8); break
-            CAMD_VSUM(1); CAMD_VSUM(3); CAMD_VSUM(5); CAMD_VSUM(7); CAMD_VSUM(9); CAMD_VSUM(11);
+                CAMD_VSUM(1); CAMD_VSUM(3); CAMD_VSUM(5); CAMD_VSUM(7); CAMD_VSUM(9); CAMD_VSUM(11);
 #undef CAMD_VSUM
-            default:
-                hipLaunchKernelGGL(k_vsum, vgrid, dim3(256), (size_t)(2 * g.SW2 + 1) * 256 * sizeof(uint4), st, hs4, c4,
-                                   g, h->vol_elems / 8);
+                default:
+                    hipLaunchKernelGGL(k_vsum<false>, vgrid, dim3(256), ring_lds, st, hs4, c4, g, h->vol_elems / 8, VSUM_ROWS);
+            }
         }
         CAMD_LAUNCH_CHECK();
     }

@@ -1,0 +1,270 @@
+// sgbm_cost.hpp -- the matching-cost volume in ONE pass: calcPixelCostBT + blockSize x blockSize box sum + P2
+// -> C[y][x][d], written once (the split pair k_hsum / k_vsum of sgbm.hip moves the volume three times).
+// Included by sgbm.hip (shares Geom).
+//
+//   C(y, x, d) = P2 + sum_{dy, dx in [-SW2, SW2]} pix(clamp(y + dy, 0, H-1), clamp(x + dx, 0, W1-1), d)
+//
+// Work decomposition ("lanes = columns, walk = rows"):
+//   * a workgroup owns a strip of 64 consecutive cost columns (64 - (K-1) of them are outputs, K-1 the
+//     horizontal halo), a block of up to 128 disparities and a chunk of rows that it walks top to bottom;
+//   * lane l of every wave is column xs0 + l; wave w owns DL consecutive disparities, so a lane computes DL
+//     pixel costs per row: its left-image operands are loaded once per row, the right-image operands of
+//     consecutive disparities are consecutive LDS entries (lane stride = one entry: conflict-free b128 reads);
+//   * the horizontal box sum is a trailing window over LANES: wave-wide DPP shifts (wave_shr:1) folded into
+//     v_add_u32 on two packed u16 costs at a time (sums stay below 2^16, no carry between the halves);
+//   * the vertical box sum is a running sum down the rows, the K rows of the window in a register ring
+//     (the row loop is unrolled by K, every ring index is static);
+//   * the BT operands of a row -- per image column (p, min(p, (p+l)/2, (p+r)/2), max(...)) with p = clipped
+//     x-Sobel | raw << 16 -- are staged in LDS two rows ahead of their use in two phases (planes, then
+//     entries), double-buffered, so the row loop has ONE barrier per row.
+// HBM traffic: the two images in, V out.
+//
+// SAT = true restates the int16 SATURATION of OpenCV's CV_SIMD build (v_int16 operator+ / operator- saturate)
+// in the vertical recurrence, in OpenCV's operation order: column 0  C = (Cprev + hsumAdd) - hsumSub, columns
+// >= 1  C = (Cprev - hsumSub) + hsumAdd, first row  C = P2 + (SH2+1)*h(0) + h(1) + ...; the recurrence then
+// has to start at row 0 (one row chunk).  SAT = false wraps modulo 2^16 like the scalar build's (CostType)
+// casts.  The two agree whenever K*K*cn*(2*ftzero + 63) + P2 <= 32767.
+#pragma once
+
+namespace camd {
+
+static constexpr int COST_DL = 8;  // disparities per lane
+#ifndef CAMD_COST_MIN_WAVES
+#define CAMD_COST_MIN_WAVES 4  // occupancy target (waves per SIMD) the register allocator works to
+#endif
+
+// n applications of the one-lane wave shift (lane i <- lane i-1, lane 0 <- 0)
+template <int N>
+__device__ __forceinline__ uint32_t wave_shr(uint32_t v)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) v = dpp_perm<DPP_WAVE_SHR1>(v);
+    return v;
+}
+
+// trailing window sum over lanes: out(l) = p(l) + p(l-1) + ... + p(l-K+1), by doubling
+template <int K>
+__device__ __forceinline__ uint32_t lane_window_sum(uint32_t p)
+{
+    if (K == 1) return p;
+    const uint32_t w2 = p + wave_shr<1>(p);
+    if (K == 3) return p + wave_shr<1>(w2);
+    if (K == 5) {
+        const uint32_t w4 = w2 + wave_shr<2>(w2);
+        return p + wave_shr<1>(w4);
+    }
+    if (K == 7) {
+        const uint32_t w3 = p + wave_shr<1>(w2);
+        const uint32_t w6 = w3 + wave_shr<3>(w3);
+        return p + wave_shr<1>(w6);
+    }
+    if (K == 9) {
+        const uint32_t w4 = w2 + wave_shr<2>(w2);
+        const uint32_t w8 = w4 + wave_shr<4>(w4);
+        return p + wave_shr<1>(w8);
+    }
+    // K == 11
+    const uint32_t w4 = w2 + wave_shr<2>(w2);
+    const uint32_t w5 = p + wave_shr<1>(w4);
+    const uint32_t w10 = w5 + wave_shr<5>(w5);
+    return p + wave_shr<1>(w10);
+}
+
+static inline size_t cost_lds_bytes(int cn, int nwaves)
+{
+    const int es = cn == 1 ? 4 : 12, dw = nwaves * COST_DL;
+    const int nr = 64 + dw - 1, nl = 64;
+    return ((size_t)2 * (nr + nl) * es + (size_t)2 * (nr + nl + 4) * cn) * 4;
+}
+
+template <int CN, int K, bool SAT>
+__global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                               size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
+                                               Geom g, int rb, int nchunks, size_t vol_stride)
+{
+    constexpr int DL = COST_DL;
+    constexpr int ES = CN == 1 ? 4 : 12;  // dwords per staged entry: (p, lo, hi) per channel, padded to 16 bytes
+    constexpr int EV = ES / 4;
+    constexpr int NP = DL / 2;            // packed cost registers per lane
+    constexpr int SW2 = K / 2;
+    constexpr int XS = 64 - (K - 1);      // output columns per strip
+    extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6, DW = NW * DL;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int chunk = blockIdx.y % nchunks, dblk = blockIdx.y / nchunks, pair = blockIdx.z;
+    const int W1 = g.W1, H = g.H;
+    const int xo0 = blockIdx.x * XS, xs0 = xo0 - SW2;                 // first output column, column of lane 0
+    const int cmin = max(xs0, 0), cmax = min(xs0 + 63, W1 - 1);       // clamped column range of the strip
+    const int cx = min(max(xs0 + lane, 0), W1 - 1);                   // this lane's (clamped) cost column
+    const int db = dblk * DW;                                         // first disparity index of the block
+    const int NL = cmax - cmin + 1, NR = NL + DW - 1;                 // staged left / right image columns
+    const int lcol0 = cmin + g.minX1;                                 // image column of left entry 0
+    const int rcol0 = cmin + g.minX1 - g.minD - (db + DW - 1);        // image column of right entry 0
+    const int NRmax = 64 + DW - 1, NLmax = 64;
+    const int esz = (NRmax + NLmax) * ES, psz = (NRmax + NLmax + 4) * CN;
+    uint32_t* const Ebuf = cs_lds;            // [2][esz]: right entries, then left entries
+    uint32_t* const Pbuf = cs_lds + 2 * esz;  // [2][psz]: right planes (+1 halo column each side), then left
+
+    const uint8_t* imgL = left + (size_t)pair * image_stride;
+    const uint8_t* imgR = right + (size_t)pair * image_stride;
+    const int ftz = g.ftzero;
+    const uint32_t ftz2 = (uint32_t)ftz | ((uint32_t)ftz << 16);
+
+    // rows: step r of the walk handles image row clamp(y0 - SW2 + r); output row y0 + r - (K-1)
+    const int y0 = chunk * rb, y1 = min(y0 + rb, H);
+    const int nsteps = (y1 - y0) + K - 1;
+    auto row_of = [&](int r) { return min(max(y0 - SW2 + r, 0), H - 1); };
+
+    // ---- staging phase A: planes of one image row (halo columns included) -----------------------------------
+    auto plane = [&](const uint8_t* img, int y, int col, int c) -> uint32_t {
+        if (col <= 0 || col >= g.W - 1) return ftz2;  // OpenCV: columns 0 and W-1 of every plane hold tab[0]
+        const uint8_t* r0 = img + (size_t)y * pitch + (size_t)col * CN + c;
+        const uint8_t* rm = img + (size_t)(y > 0 ? y - 1 : y) * pitch + (size_t)col * CN + c;
+        const uint8_t* rp = img + (size_t)(y < H - 1 ? y + 1 : y) * pitch + (size_t)col * CN + c;
+        int gq = ((int)r0[CN] - (int)r0[-CN]) * 2 + ((int)rm[CN] - (int)rm[-CN]) + ((int)rp[CN] - (int)rp[-CN]);
+        gq = min(max(gq, -ftz), ftz) + ftz;
+        return (uint32_t)gq | ((uint32_t)r0[0] << 16);
+    };
+    auto stage_planes = [&](int y, uint32_t* P) {
+        const int nr = NR + 2, n = nr + NL + 2;
+        for (int i = tid; i < n; i += nthreads) {
+            const bool isr = i < nr;
+            const int k = isr ? i : i - nr;
+            const int col = (isr ? rcol0 : lcol0) - 1 + k;
+            uint32_t* dst = P + (isr ? 0 : (NRmax + 2) * CN) + k * CN;
+#pragma unroll
+            for (int c = 0; c < CN; c++) dst[c] = plane(isr ? imgR : imgL, y, col, c);
+        }
+    };
+    // ---- staging phase B: entries (p, min(p, (p+l)/2, (p+r)/2), max(...)) from the planes --------------------
+    auto stage_entries = [&](const uint32_t* P, uint32_t* E) {
+        const int n = NR + NL;
+        // assigned from the LAST thread downwards: phase A keeps the first waves busy
+        for (int i = nthreads - 1 - tid; i < n; i += nthreads) {
+            const bool isr = i < NR;
+            const int k = isr ? i : i - NR;
+            const int col = (isr ? rcol0 : lcol0) + k;
+            const uint32_t* src = P + (isr ? 0 : (NRmax + 2) * CN) + (k + 1) * CN;
+            uint32_t* dst = E + (isr ? 0 : NRmax * ES) + k * ES;
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                const uint32_t u = src[c], l = src[c - CN], r = src[c + CN];
+                const uint32_t ul = col > 0 ? pk_lshr_u16(pk_add_u16(u, l), 0x00010001u) : u;
+                const uint32_t ur = col < g.W - 1 ? pk_lshr_u16(pk_add_u16(u, r), 0x00010001u) : u;
+                dst[c * 3] = u;
+                dst[c * 3 + 1] = pk_min_u16(pk_min_u16(ul, ur), u);
+                dst[c * 3 + 2] = pk_max_u16(pk_max_u16(ul, ur), u);
+            }
+        }
+    };
+
+    stage_planes(row_of(0), Pbuf);
+    __syncthreads();
+    stage_entries(Pbuf, Ebuf);
+    stage_planes(row_of(1), Pbuf + psz);
+    __syncthreads();
+
+    // ---- per-lane constants -----------------------------------------------------------------------------------
+    const int d0 = db + w * DL;                               // first disparity index of this wave
+    uint32_t keep[NP];                                        // padded disparities d >= D carry pix = 0 (C = P2)
+#pragma unroll
+    for (int k = 0; k < NP; k++)
+        keep[k] = (d0 + 2 * k < g.D ? 0xffffu : 0u) | (d0 + 2 * k + 1 < g.D ? 0xffff0000u : 0u);
+    const int eoff_l = NRmax * EV + (cx - cmin) * EV;                              // uint4 index of the left entry
+    const int eoff_r = ((cx - cmin) + DW - 1 - w * DL - (DL - 1)) * EV;            // right entry of cell DL-1
+    const int xo = xo0 + lane - (K - 1);                                           // output column of this lane
+    const bool writer = lane >= K - 1 && xo < W1 && d0 < g.Dp;
+    const bool first_col = xo == 0;
+    uint16_t* const outp = Cout + (size_t)pair * vol_stride + (size_t)(writer ? xo : 0) * g.Dp + d0;
+
+    const uint32_t p2 = dup16((uint32_t)g.P2);
+    uint32_t acc[NP], ring[K][NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) acc[k] = p2;
+#pragma unroll
+    for (int u = 0; u < K; u++)
+#pragma unroll
+        for (int k = 0; k < NP; k++) ring[u][k] = 0;
+
+    for (int r0 = 0; r0 < nsteps; r0 += K) {
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const int r = r0 + u;
+            if (r < nsteps) {  // uniform
+                // phase A for row r+2 (its global loads are in flight during the arithmetic below)
+                stage_planes(row_of(r + 2), Pbuf + (r & 1) * psz);
+
+                const uint4* E4 = reinterpret_cast<const uint4*>(Ebuf + (r & 1) * esz);
+                uint32_t U[CN], U0[CN], U1[CN];
+                {
+                    const uint4* q = E4 + eoff_l;
+                    if (CN == 1) {
+                        const uint4 a = q[0];
+                        U[0] = a.x; U0[0] = a.y; U1[0] = a.z;
+                    } else {
+                        const uint4 a = q[0], b = q[1], c = q[2];
+                        U[0] = a.x; U0[0] = a.y; U1[0] = a.z;
+                        U[1 % CN] = a.w; U0[1 % CN] = b.x; U1[1 % CN] = b.y;
+                        U[2 % CN] = b.z; U0[2 % CN] = b.w; U1[2 % CN] = c.x;
+                    }
+                }
+                uint32_t cost[DL];
+#pragma unroll
+                for (int j = 0; j < DL; j++) {
+                    const uint4* q = E4 + eoff_r + (DL - 1 - j) * EV;
+                    uint32_t V[CN], V0[CN], V1[CN];
+                    if (CN == 1) {
+                        const uint4 a = q[0];
+                        V[0] = a.x; V0[0] = a.y; V1[0] = a.z;
+                    } else {
+                        const uint4 a = q[0], b = q[1], c = q[2];
+                        V[0] = a.x; V0[0] = a.y; V1[0] = a.z;
+                        V[1 % CN] = a.w; V0[1 % CN] = b.x; V1[1 % CN] = b.y;
+                        V[2 % CN] = b.z; V0[2 % CN] = b.w; V1[2 % CN] = c.x;
+                    }
+                    uint32_t a32 = 0;
+#pragma unroll
+                    for (int c = 0; c < CN; c++) {
+                        // c0 = max(0, u - v1, v0 - u), c1 = max(0, v - u1, u0 - v): at most one term of each pair
+                        // is non-zero, so OR of the saturating differences is their max
+                        const uint32_t a = pk_subsat_u16(U[c], V1[c]) | pk_subsat_u16(V0[c], U[c]);
+                        const uint32_t b = pk_subsat_u16(V[c], U1[c]) | pk_subsat_u16(U0[c], V[c]);
+                        uint32_t m = pk_min_u16(a, b);
+                        m = pk_lshr_u16(m, 0x00020000u);  // raw plane: cost >> 2
+                        a32 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, m),
+                                                     __builtin_bit_cast(u16x2_t, 0x00010001u), a32, false);
+                    }
+                    cost[j] = a32;
+                }
+                // pack two disparities per register, horizontal window over lanes, vertical running sum
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    const uint32_t pp = (cost[2 * k] | (cost[2 * k + 1] << 16)) & keep[k];
+                    const uint32_t T = lane_window_sum<K>(pp);
+                    const uint32_t old = ring[u][k];
+                    ring[u][k] = T;
+                    if (SAT) {
+                        // (Cprev + add) - sub in column 0 while the entering row exists (y + SH2 < H), else and
+                        // everywhere else (Cprev - sub) + add
+                        const uint32_t a0 = pk_subsat_i16(pk_addsat_i16(acc[k], T), old);
+                        const uint32_t a1 = pk_addsat_i16(pk_subsat_i16(acc[k], old), T);
+                        acc[k] = (first_col && y0 + r - (K - 1) + SW2 < H) ? a0 : a1;
+                    } else {
+                        acc[k] = pk_sub_u16(pk_add_u16(acc[k], T), old);
+                    }
+                }
+                if (r >= K - 1 && writer) {
+                    const int y = y0 + r - (K - 1);
+                    uint4* o = reinterpret_cast<uint4*>(outp + (size_t)y * W1 * g.Dp);
+                    *o = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                }
+                // phase B for row r+1
+                stage_entries(Pbuf + ((r + 1) & 1) * psz, Ebuf + ((r + 1) & 1) * esz);
+                __syncthreads();
+            }
+        }
+    }
+}
+
+}  // namespace camd

@@ -83,13 +83,18 @@ int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* st
  *   CAMD_PATH_BAND            fused band-wavefront passes (throughput; D in (32, 256])
  *   CAMD_PATH_CONCURRENT      all directions at once into per-direction volumes (latency; <= 8 pairs per call)
  * CAMD_OPT_KEEP_S 1 = the band path also stores the final S volume (for camd_sgbm_debug_copy(which = 1)). */
-enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1, CAMD_OPT_COST = 2 };
+enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1, CAMD_OPT_COST = 2, CAMD_OPT_SATURATE = 3 };
 enum { CAMD_PATH_AUTO = 0, CAMD_PATH_SCAN = 1, CAMD_PATH_BAND = 2, CAMD_PATH_CONCURRENT = 3 };
 /* CAMD_OPT_COST selects how the matching-cost volume C is built (bit-identical results):
  *   CAMD_COST_AUTO (default)  the fused kernel where it is instantiated (blockSize <= 11), else the split pair
  *   CAMD_COST_FUSED           k_cost: BT pixel cost + blockSize x blockSize box sum + P2 -> C, written once
  *   CAMD_COST_SPLIT           k_hsum (BT + horizontal sum) -> intermediate volume -> k_vsum (vertical sum) -> C */
 enum { CAMD_COST_AUTO = 0, CAMD_COST_FUSED = 1, CAMD_COST_SPLIT = 2 };
+/* CAMD_OPT_SATURATE: int16 overflow behaviour of the box-sum recurrences that build C:
+ *   1 (default)  saturate like OpenCV's CV_SIMD build (v_int16 + / -), which is what cv2 wheels run
+ *   0            wrap modulo 2^16 like OpenCV's scalar build
+ * The two differ only if blockSize^2 * channels * (2*ftzero + 63) + P2 > 32767 AND the image content drives a
+ * window sum past 32767 (e.g. blockSize >= 11 on RGB with a large preFilterCap). */
 int camd_sgbm_set_option(camd_sgbm* h, int option, int value);
 /* synchronises `stream` and reports whether a device-side bounded wait of the last computes timed out.
  * Without this call a timeout still cannot pass unnoticed: the affected call's disparities are written as

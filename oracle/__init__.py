@@ -28,7 +28,8 @@ class SgbmParams(ctypes.Structure):
 
 
 class Switches(ctypes.Structure):
-    _fields_ = [("lanczos_fix_group_lo", ctypes.c_int), ("bt_border_raw_tab0", ctypes.c_int)]
+    _fields_ = [("lanczos_fix_group_lo", ctypes.c_int), ("bt_border_raw_tab0", ctypes.c_int),
+                ("cost_saturate", ctypes.c_int)]
 
 
 def build(force=False):
@@ -258,6 +259,6 @@ def unrectify_depth(depth, M_row2, mapx, mapy):
     return out
 
 
-def set_switches(lanczos_fix_group_lo=4, bt_border_raw_tab0=1):
-    s = Switches(int(lanczos_fix_group_lo), int(bt_border_raw_tab0))
+def set_switches(lanczos_fix_group_lo=4, bt_border_raw_tab0=1, cost_saturate=1):
+    s = Switches(int(lanczos_fix_group_lo), int(bt_border_raw_tab0), int(cost_saturate))
     lib().oracle_set_switches(ctypes.byref(s))

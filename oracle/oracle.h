@@ -50,6 +50,10 @@ typedef struct oracle_switches {
     int lanczos_fix_group_lo; /* U15: first index of the 2x2 tap group that takes the weight-sum
                                  correction; OpenCV source: ksize/2 (=4 for Lanczos4) */
     int bt_border_raw_tab0;   /* U11: raw-intensity planes also get tab[0] at columns 0, W-1 (1) */
+    int cost_saturate;        /* U7: the box-sum recurrences that build C saturate to int16 like OpenCV's
+                                 universal-intrinsic v_int16 + / - / * (1, what shipped SIMD builds run;
+                                 default) or wrap like the scalar (CostType) casts (0).  Identical whenever
+                                 blockSize^2 * cn * (2*ftzero + 63) + P2 <= 32767. */
 } oracle_switches;
 void oracle_set_switches(const oracle_switches* s);
 void oracle_get_switches(oracle_switches* s);

@@ -26,9 +26,17 @@ typedef uint8_t PixType;
 enum { DISP_SHIFT = 4, DISP_SCALE = 1 << DISP_SHIFT };
 #define MAX_COST ((CostType)SHRT_MAX)
 
-static oracle_switches g_sw = {4, 1};
+static oracle_switches g_sw = {4, 1, 1};
 void oracle_set_switches(const oracle_switches* s) { g_sw = *s; }
 void oracle_get_switches(oracle_switches* s) { *s = g_sw; }
+
+/* U7: one int16 add / sub / mul of the cost-volume recurrences -- saturating (v_int16 operators of OpenCV's
+ * SIMD path) or wrapping (the scalar path's (CostType) cast) */
+static inline short cost_wrap(int v) { return (short)v; }
+static inline short cost_sat(int v) { return (short)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v)); }
+static inline short c_add(int a, int b) { return g_sw.cost_saturate ? cost_sat(a + b) : cost_wrap(a + b); }
+static inline short c_sub(int a, int b) { return g_sw.cost_saturate ? cost_sat(a - b) : cost_wrap(a - b); }
+static inline short c_mul(int a, int b) { return g_sw.cost_saturate ? cost_sat(a * b) : cost_wrap(a * b); }
 int oracle_sw_lanczos_group(void) { return g_sw.lanczos_fix_group_lo; }
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
@@ -251,11 +259,14 @@ static int compute_disparity_sgbm(const PixType* img1, const PixType* img2, int 
                         calc_pixel_cost_bt(img1, img2, step, width, height, cn, k, minD, maxD,
                                            pixDiff, tempBuf, clipTab + TAB_OFS);
 
-                        memset(hsumAdd, 0, (size_t)D * sizeof(CostType));
-                        for (x = 0; x <= SW2 * D; x += D) {
-                            int scale = x == 0 ? SW2 + 1 : 1;
-                            for (d = 0; d < D; d++)
-                                hsumAdd[d] = (CostType)(hsumAdd[d] + pixDiff[x + d] * scale);
+                        /* Operation order as in OpenCV's CV_SIMD branches (it only matters when cost_saturate
+                         * is on and a value crosses 32767): hsumAdd[0] = pix[0]*(SW2+1) + pix[1] + ...;
+                         * hv = hsumAdd[x-1] - pixSub + pixAdd; column 0: C = Cprev + hsumAdd - hsumSub;
+                         * columns >= 1: C = Cprev - hsumSub + hv; first row: C = C + hv*scale. */
+                        for (d = 0; d < D; d++) {
+                            CostType h = c_mul(pixDiff[d], SW2 + 1);
+                            for (x = D; x <= SW2 * D; x += D) h = c_add(h, pixDiff[x + d]);
+                            hsumAdd[d] = h;
                         }
 
                         if (y > 0) {
@@ -263,28 +274,28 @@ static int compute_disparity_sgbm(const PixType* img1, const PixType* img2, int 
                             const CostType* Cprev = GET_C(y - 1);
 
                             for (d = 0; d < D; d++)
-                                C[d] = (CostType)(Cprev[d] + hsumAdd[d] - hsumSub[d]);
+                                C[d] = c_sub(c_add(Cprev[d], hsumAdd[d]), hsumSub[d]);
 
                             for (x = D; x < width1 * D; x += D) {
                                 const CostType* pixAdd = pixDiff + imin(x + SW2 * D, (width1 - 1) * D);
                                 const CostType* pixSub = pixDiff + imax(x - (SW2 + 1) * D, 0);
                                 for (d = 0; d < D; d++) {
-                                    int hv = hsumAdd[x + d] =
-                                        (CostType)(hsumAdd[x - D + d] + pixAdd[d] - pixSub[d]);
-                                    C[x + d] = (CostType)(Cprev[x + d] + hv - hsumSub[x + d]);
+                                    CostType hv = c_add(c_sub(hsumAdd[x - D + d], pixSub[d]), pixAdd[d]);
+                                    hsumAdd[x + d] = hv;
+                                    C[x + d] = c_add(c_sub(Cprev[x + d], hsumSub[x + d]), hv);
                                 }
                             }
                         } else {
                             int scale = k == 0 ? SH2 + 1 : 1;
                             for (d = 0; d < D; d++)
-                                C[d] = (CostType)(C[d] + hsumAdd[d] * scale);
+                                C[d] = c_add(C[d], c_mul(hsumAdd[d], scale));
                             for (x = D; x < width1 * D; x += D) {
                                 const CostType* pixAdd = pixDiff + imin(x + SW2 * D, (width1 - 1) * D);
                                 const CostType* pixSub = pixDiff + imax(x - (SW2 + 1) * D, 0);
                                 for (d = 0; d < D; d++) {
-                                    CostType hv = (CostType)(hsumAdd[x - D + d] + pixAdd[d] - pixSub[d]);
+                                    CostType hv = c_add(c_sub(hsumAdd[x - D + d], pixSub[d]), pixAdd[d]);
                                     hsumAdd[x + d] = hv;
-                                    C[x + d] = (CostType)(C[x + d] + hv * scale);
+                                    C[x + d] = c_add(C[x + d], c_mul(hv, scale));
                                 }
                             }
                         }
@@ -293,10 +304,10 @@ static int compute_disparity_sgbm(const PixType* img1, const PixType* img2, int 
                             const CostType* hsumSub = GET_HSUM(imax(y - SH2 - 1, 0));
                             const CostType* Cprev = GET_C(y - 1);
                             for (x = 0; x < width1 * D; x++)
-                                C[x] = (CostType)(Cprev[x] + hsumAdd[x] - hsumSub[x]);
+                                C[x] = c_add(c_sub(Cprev[x], hsumSub[x]), hsumAdd[x]);
                         } else {
                             for (x = 0; x < width1 * D; x++)
-                                C[x] = (CostType)(C[x] + hsumAdd[x]);
+                                C[x] = c_add(C[x], hsumAdd[x]);
                         }
                     }
                 }

@@ -1,5 +1,6 @@
 #!/bin/bash
 # build a measurement variant of the library: tools/build_dbg.sh NAME -DFLAG [-DFLAG...]  -> calibrating_amd/lib/dbg_NAME.so
+# (load it with `python bench.py --lib calibrating_amd/lib/dbg_NAME.so`)
 NAME=$1; shift
 cd "$(dirname "$0")/../calibrating_amd/csrc"
 mkdir -p ../lib/dbg_$NAME
