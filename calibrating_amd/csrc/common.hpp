@@ -98,6 +98,7 @@ enum : int {
     DPP_QUAD_XOR2 = 0x4E,  // quad_perm:[2,3,0,1]
     DPP_ROW_SHL1 = 0x101,  // lane i <- lane i+1 (within the row)
     DPP_ROW_SHR1 = 0x111,  // lane i <- lane i-1 (within the row)
+    DPP_WAVE_SHL1 = 0x130, // lane i <- lane i+1 (whole wave)
     DPP_WAVE_SHR1 = 0x138, // lane i <- lane i-1 (whole wave)
     DPP_ROW_MIRROR = 0x140,
     DPP_ROW_HALF_MIRROR = 0x141

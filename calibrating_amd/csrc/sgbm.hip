@@ -1006,7 +1006,8 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     const bool fused = K <= 11 && h->cost_path != CAMD_COST_SPLIT;
     MARK(ST_COST);
     if (fused) {
-        const int nw = g.Dp / COST_DL < 16 ? g.Dp / COST_DL : 16;       // waves per workgroup
+        // waves per workgroup: one per 8 disparities, at least 4 (the staging needs up to 3 waves of lanes)
+        const int nw = g.Dp / COST_DL < 4 ? 4 : (g.Dp / COST_DL < 16 ? g.Dp / COST_DL : 16);
         const int ndblk = div_up(g.Dp, nw * COST_DL);                   // disparity blocks of <= 128
         const int nstrips = div_up(g.W1, 64 - (K - 1));
         // row chunks: enough workgroups for ~32 rounds over the chip, but the saturating recurrence must start at row 0

@@ -15,8 +15,9 @@
 //   * the vertical box sum is a running sum down the rows, the K rows of the window in a register ring
 //     (the row loop is unrolled by K, every ring index is static);
 //   * the BT operands of a row -- per image column (p, min(p, (p+l)/2, (p+r)/2), max(...)) with p = clipped
-//     x-Sobel | raw << 16 -- are staged in LDS two rows ahead of their use in two phases (planes, then
-//     entries), double-buffered, so the row loop has ONE barrier per row.
+//     x-Sobel | raw << 16 -- are staged in LDS one row ahead of their use by a few "staging" waves: lane =
+//     image column, the column's three rows fetched as unaligned dwords a step earlier, x-neighbours by DPP
+//     wave shifts; double-buffered, so the row loop has ONE barrier per row.
 // HBM traffic: the two images in, V out.
 //
 // SAT = true restates the int16 SATURATION of OpenCV's CV_SIMD build (v_int16 operator+ / operator- saturate)
@@ -74,7 +75,7 @@ static inline size_t cost_lds_bytes(int cn, int nwaves)
 {
     const int es = cn == 1 ? 4 : 12, dw = nwaves * COST_DL;
     const int nr = 64 + dw - 1, nl = 64;
-    return ((size_t)2 * (nr + nl) * es + (size_t)2 * (nr + nl + 4) * cn) * 4;
+    return (size_t)2 * (nr + nl) * es * 4;
 }
 
 template <int CN, int K, bool SAT>
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6, DW = NW * DL;
-    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int tid = threadIdx.x;
     const int chunk = blockIdx.y % nchunks, dblk = blockIdx.y / nchunks, pair = blockIdx.z;
     const int W1 = g.W1, H = g.H;
     const int xo0 = blockIdx.x * XS, xs0 = xo0 - SW2;                 // first output column, column of lane 0
@@ -102,9 +103,8 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     const int lcol0 = cmin + g.minX1;                                 // image column of left entry 0
     const int rcol0 = cmin + g.minX1 - g.minD - (db + DW - 1);        // image column of right entry 0
     const int NRmax = 64 + DW - 1, NLmax = 64;
-    const int esz = (NRmax + NLmax) * ES, psz = (NRmax + NLmax + 4) * CN;
-    uint32_t* const Ebuf = cs_lds;            // [2][esz]: right entries, then left entries
-    uint32_t* const Pbuf = cs_lds + 2 * esz;  // [2][psz]: right planes (+1 halo column each side), then left
+    const int esz = (NRmax + NLmax) * ES;
+    uint32_t* const Ebuf = cs_lds;  // [2][esz]: right entries, then left entries
 
     const uint8_t* imgL = left + (size_t)pair * image_stride;
     const uint8_t* imgR = right + (size_t)pair * image_stride;
@@ -116,53 +116,99 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     const int nsteps = (y1 - y0) + K - 1;
     auto row_of = [&](int r) { return min(max(y0 - SW2 + r, 0), H - 1); };
 
-    // ---- staging phase A: planes of one image row (halo columns included) -----------------------------------
-    auto plane = [&](const uint8_t* img, int y, int col, int c) -> uint32_t {
-        if (col <= 0 || col >= g.W - 1) return ftz2;  // OpenCV: columns 0 and W-1 of every plane hold tab[0]
-        const uint8_t* r0 = img + (size_t)y * pitch + (size_t)col * CN + c;
-        const uint8_t* rm = img + (size_t)(y > 0 ? y - 1 : y) * pitch + (size_t)col * CN + c;
-        const uint8_t* rp = img + (size_t)(y < H - 1 ? y + 1 : y) * pitch + (size_t)col * CN + c;
-        int gq = ((int)r0[CN] - (int)r0[-CN]) * 2 + ((int)rm[CN] - (int)rm[-CN]) + ((int)rp[CN] - (int)rp[-CN]);
-        gq = min(max(gq, -ftz), ftz) + ftz;
-        return (uint32_t)gq | ((uint32_t)r0[0] << 16);
-    };
-    auto stage_planes = [&](int y, uint32_t* P) {
-        const int nr = NR + 2, n = nr + NL + 2;
-        for (int i = tid; i < n; i += nthreads) {
-            const bool isr = i < nr;
-            const int k = isr ? i : i - nr;
-            const int col = (isr ? rcol0 : lcol0) - 1 + k;
-            uint32_t* dst = P + (isr ? 0 : (NRmax + 2) * CN) + k * CN;
-#pragma unroll
-            for (int c = 0; c < CN; c++) dst[c] = plane(isr ? imgR : imgL, y, col, c);
+    // ---- staging: one lane = one image column, neighbours by wave-wide DPP shifts ---------------------------------
+    // The staged columns (NR of the right image, NL of the left) are cut into pieces of <= 60 columns; a piece sits
+    // in consecutive lanes of ONE wave with two extra columns on each side (p needs the vertical sums of x-1, x+1;
+    // the entry needs p of x-1, x+1).  Every lane finds its piece once; waves without a piece skip the staging.
+    int st_k = 0, st_lo = 0, st_hi = 0, st_img = -1;
+    {
+        int v = 0;
+        for (int sg = 0; sg < 2; sg++) {
+            const int n = sg ? NL : NR;
+            for (int e = 0; e < n;) {
+                int room = 64 - (v & 63);
+                if (room < 5) { v += room; room = 64; }
+                const int len = min(n - e, room - 4);
+                if (tid >= v && tid < v + len + 4) { st_img = sg; st_k = e + (tid - v) - 2; st_lo = e; st_hi = e + len; }
+                v += len + 4;
+                e += len;
+            }
+        }
+    }
+    const bool stager = st_img >= 0;
+    const bool st_store = stager && st_k >= st_lo && st_k < st_hi;
+    const int st_col = (st_img == 1 ? lcol0 : rcol0) + st_k;
+    const bool st_inside = st_col > 0 && st_col < g.W - 1;  // OpenCV: columns 0 and W-1 of every plane hold tab[0]
+    const int st_ccol = min(max(st_col, 0), g.W - 1);
+    // RGB pixels are fetched as ONE unaligned dword (R | G << 8 | B << 16 | next byte); the last column of a row is
+    // fetched one byte early and shifted so that no load reaches past the row
+    const bool st_last = CN == 3 && st_ccol == g.W - 1;
+    const uint8_t* st_ptr = (st_img == 1 ? imgL : imgR) + (size_t)st_ccol * CN - (st_last ? 1 : 0);
+    const uint32_t st_shift = st_last ? 8u : 0u;
+    uint32_t* const st_dst = Ebuf + (st_img == 1 ? NRmax * ES : 0) + st_k * ES;  // + buffer * esz
+
+    uint32_t rowA = 0, rowB = 0, rowC = 0;  // the three image rows of the column being staged (in flight)
+    auto fetch_rows = [&](int y) {
+        if (stager) {
+            const uint8_t* pm = st_ptr + (size_t)(y > 0 ? y - 1 : y) * pitch;
+            const uint8_t* p0 = st_ptr + (size_t)y * pitch;
+            const uint8_t* pp = st_ptr + (size_t)(y < H - 1 ? y + 1 : y) * pitch;
+            if (CN == 1) {
+                rowA = *pm; rowB = *p0; rowC = *pp;
+            } else {
+                __builtin_memcpy(&rowA, pm, 4);
+                __builtin_memcpy(&rowB, p0, 4);
+                __builtin_memcpy(&rowC, pp, 4);
+            }
         }
     };
-    // ---- staging phase B: entries (p, min(p, (p+l)/2, (p+r)/2), max(...)) from the planes --------------------
-    auto stage_entries = [&](const uint32_t* P, uint32_t* E) {
-        const int n = NR + NL;
-        // assigned from the LAST thread downwards: phase A keeps the first waves busy
-        for (int i = nthreads - 1 - tid; i < n; i += nthreads) {
-            const bool isr = i < NR;
-            const int k = isr ? i : i - NR;
-            const int col = (isr ? rcol0 : lcol0) + k;
-            const uint32_t* src = P + (isr ? 0 : (NRmax + 2) * CN) + (k + 1) * CN;
-            uint32_t* dst = E + (isr ? 0 : NRmax * ES) + k * ES;
+    auto stage_entries = [&](int buf) {
+        if (stager) {  // wave-uniform up to the last staging wave
+            uint32_t u[CN], lo[CN], hi[CN];
+            const uint32_t a = rowA >> st_shift, b = rowB >> st_shift, c = rowC >> st_shift;
 #pragma unroll
-            for (int c = 0; c < CN; c++) {
-                const uint32_t u = src[c], l = src[c - CN], r = src[c + CN];
-                const uint32_t ul = col > 0 ? pk_lshr_u16(pk_add_u16(u, l), 0x00010001u) : u;
-                const uint32_t ur = col < g.W - 1 ? pk_lshr_u16(pk_add_u16(u, r), 0x00010001u) : u;
-                dst[c * 3] = u;
-                dst[c * 3 + 1] = pk_min_u16(pk_min_u16(ul, ur), u);
-                dst[c * 3 + 2] = pk_max_u16(pk_max_u16(ul, ur), u);
+            for (int ch = 0; ch < CN; ch++) {
+                // vertical part of the x-Sobel: s = I(y-1) + 2 I(y) + I(y+1) -- the three rows of this channel
+                // gathered into one dword, then one dot product with (1, 2, 1)
+                const uint32_t t = __builtin_amdgcn_perm(b, a, 0x0c0c0400u + 0x00000101u * ch);      // (a.ch, b.ch, 0, 0)
+                const uint32_t t3 = __builtin_amdgcn_perm(c, t, 0x0c040100u + 0x00010000u * ch);     // (a.ch, b.ch, c.ch, 0)
+                const uint32_t sv = __builtin_amdgcn_udot4(t3, 0x00010201u, 0u, false);
+                // gradient = s(x+1) - s(x-1), clipped to [-ftz, ftz], + ftz;  p = gradient | raw << 16
+                // (the subtrahend passes through an empty asm so that the DPP move is NOT folded into the subtraction:
+                // the folded form, v_subrev_u32_dpp, measured wrong on gfx950 -- it returned shr(src1) - src0)
+                uint32_t sl = dpp_perm<DPP_WAVE_SHR1>(sv);
+                asm volatile("" : "+v"(sl));
+                const int gq = (int)dpp_perm<DPP_WAVE_SHL1>(sv) - (int)sl;
+                const uint32_t gc = (uint32_t)(min(max(gq, -ftz), ftz) + ftz);
+                const uint32_t raw = (b >> (8 * ch)) & 0xffu;
+                u[ch] = st_inside ? (gc | (raw << 16)) : ftz2;
+            }
+#pragma unroll
+            for (int ch = 0; ch < CN; ch++) {
+                // half-pixel interval: columns outside the image carry ftz2 like the border columns, so the
+                // "no neighbour at the image edge" rule (use p itself) needs no special case
+                const uint32_t l = dpp_perm<DPP_WAVE_SHR1>(u[ch]), r = dpp_perm<DPP_WAVE_SHL1>(u[ch]);
+                const uint32_t ul = pk_lshr_u16(pk_add_u16(u[ch], l), 0x00010001u);
+                const uint32_t ur = pk_lshr_u16(pk_add_u16(u[ch], r), 0x00010001u);
+                lo[ch] = pk_min_u16(pk_min_u16(ul, ur), u[ch]);
+                hi[ch] = pk_max_u16(pk_max_u16(ul, ur), u[ch]);
+            }
+            if (st_store) {
+                uint4* d4 = reinterpret_cast<uint4*>(st_dst + buf * esz);
+                if (CN == 1) {
+                    d4[0] = make_uint4(u[0], lo[0], hi[0], 0u);
+                } else {
+                    d4[0] = make_uint4(u[0], lo[0], hi[0], u[1 % CN]);
+                    d4[1] = make_uint4(lo[1 % CN], hi[1 % CN], u[2 % CN], lo[2 % CN]);
+                    d4[2] = make_uint4(hi[2 % CN], 0u, 0u, 0u);
+                }
             }
         }
     };
 
-    stage_planes(row_of(0), Pbuf);
-    __syncthreads();
-    stage_entries(Pbuf, Ebuf);
-    stage_planes(row_of(1), Pbuf + psz);
+    fetch_rows(row_of(0));
+    stage_entries(0);
+    fetch_rows(row_of(1));  // consumed at the end of step 0
     __syncthreads();
 
     // ---- per-lane constants -----------------------------------------------------------------------------------
@@ -171,8 +217,11 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
 #pragma unroll
     for (int k = 0; k < NP; k++)
         keep[k] = (d0 + 2 * k < g.D ? 0xffffu : 0u) | (d0 + 2 * k + 1 < g.D ? 0xffff0000u : 0u);
-    const int eoff_l = NRmax * EV + (cx - cmin) * EV;                              // uint4 index of the left entry
-    const int eoff_r = ((cx - cmin) + DW - 1 - w * DL - (DL - 1)) * EV;            // right entry of cell DL-1
+    int eoff_l = NRmax * EV + (cx - cmin) * EV;                                    // uint4 index of the left entry
+    int eoff_r = ((cx - cmin) + DW - 1 - w * DL - (DL - 1)) * EV;                  // right entry of cell DL-1
+    // opaque to the optimiser: the per-cell entries are then reached with non-negative immediate offsets from this
+    // base (re-associated, the lowest address would be a negative offset and cost a VALU add per LDS read)
+    asm volatile("" : "+v"(eoff_l), "+v"(eoff_r));
     const int xo = xo0 + lane - (K - 1);                                           // output column of this lane
     const bool writer = lane >= K - 1 && xo < W1 && d0 < g.Dp;
     const bool first_col = xo == 0;
@@ -192,8 +241,6 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
         for (int u = 0; u < K; u++) {
             const int r = r0 + u;
             if (r < nsteps) {  // uniform
-                // phase A for row r+2 (its global loads are in flight during the arithmetic below)
-                stage_planes(row_of(r + 2), Pbuf + (r & 1) * psz);
 
                 const uint4* E4 = reinterpret_cast<const uint4*>(Ebuf + (r & 1) * esz);
                 uint32_t U[CN], U0[CN], U1[CN];
@@ -259,8 +306,9 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
                     uint4* o = reinterpret_cast<uint4*>(outp + (size_t)y * W1 * g.Dp);
                     *o = make_uint4(acc[0], acc[1], acc[2], acc[3]);
                 }
-                // phase B for row r+1
-                stage_entries(Pbuf + ((r + 1) & 1) * psz, Ebuf + ((r + 1) & 1) * esz);
+                // entries of row r+1 from the rows fetched one step ago; then fetch for row r+2
+                stage_entries((r + 1) & 1);
+                fetch_rows(row_of(r + 2));
                 __syncthreads();
             }
         }
