@@ -9,8 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# CAMD_LIB lets a measurement run load an experimental build of the same ABI (A/B kernel variants)
-LIB_PATH = os.environ.get("CAMD_LIB") or os.path.join(_HERE, "lib", "libcalibrating_amd.so")
+# (bench.py --lib points this at an experimental build of the same ABI before the first call: A/B kernel variants)
+LIB_PATH = os.path.join(_HERE, "lib", "libcalibrating_amd.so")
 _lib = None
 
 c_void_p, c_int, c_size_t, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
@@ -78,6 +78,7 @@ SIGNATURES = {
                                           c_void_p, c_void_p]),
     "camd_project_depth": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p]),
+    "camd_set_global_option": (c_int, [c_int, c_int]),
     "camd_lanczos4_table_host": (c_int, [c_void_p]),
     "camd_bilinear_table_host": (c_int, [c_void_p]),
     "camd_resize_linear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -8,6 +8,7 @@
 // a 32x32-entry table (sum forced to 32768), int32 accumulate, (sum + 16384) >> 15, BORDER_CONSTANT 0.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -18,70 +19,89 @@ enum { INTER_BITS = 5, INTER_TAB_SIZE = 32, COEF_BITS = 15, COEF_SCALE = 1 << 15
 
 static inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
 
-// 1-D Lanczos-4 weights at phase x in [0,1): taps at offsets -3..4
-static void lanczos4_1d(float x, float* coeffs)
+// ---- fixed-point interpolation tables (host, built once per process and option value) ------------------------
+// The table of a KS-tap kernel has 32 x 32 entries (one per 1/32-pixel phase pair), each KS*KS int16 weights
+// = round(wy[ky] * wx[kx] * 32768) whose sum is then forced to exactly 32768.
+//
+// U15: which taps take that correction is a process-wide option shared with the oracle's switch
+// of the same name, so the two cannot drift apart: the correction looks at the 2x2 taps (k1, k2) in
+// [lo, lo+2) x [lo, lo+2) of the entry, adds the missing weight to the largest of them or removes the excess from
+// the smallest.  lo = KS/2 by default (OpenCV's loop bounds as recalled; 4 for Lanczos-4), settable to KS/2 - 1
+// through camd_set_global_option(CAMD_GOPT_LANCZOS_FIX_GROUP_LO, 3).
+static int g_fix_group_lo8 = 4;
+
+// Phase table of the 1-D kernels, [32][KS] float32.
+static std::vector<float> phase_weights(int ks)
 {
-    static const double s45 = 0.70710678118654752440084436210485;
-    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45},
-                                   {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
-    const double PI = 3.1415926535897932384626433832795;
-    float sum = 0;
-    double y0 = -(x + 3) * PI * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
-    for (int i = 0; i < 8; i++) {
-        float y0_ = (x + 3 - i);
-        if (std::fabs(y0_) >= 1e-6f) {
-            double y = -y0_ * PI * 0.25;
-            coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
-        } else {
-            coeffs[i] = 1e30f;  // exact hit: takes all the weight after normalisation
+    std::vector<float> w((size_t)INTER_TAB_SIZE * ks);
+    if (ks == 2) {  // bilinear: (1 - t, t)
+        for (int p = 0; p < INTER_TAB_SIZE; p++) {
+            const float t = p * (1.f / INTER_TAB_SIZE);
+            w[p * 2] = 1.f - t;
+            w[p * 2 + 1] = t;
         }
-        sum += coeffs[i];
+        return w;
     }
-    sum = 1.f / sum;
-    for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+    // Lanczos-4, taps at offsets -3..4 from the integer position: w_k ~ sin(pi d) sin(pi d / 4) / d^2 with
+    // d = t + 3 - k, evaluated the way OpenCV does -- sin(pi d) sin(pi d/4) is expanded into the sine and
+    // cosine of ONE angle a = -(t+3) pi/4 with a table of eighth-turn rotations, in double, divided by (pi d / 4)^2,
+    // rounded to float; a tap the sample falls on (|d| < 1e-6) gets 1e30; the eight floats are then scaled by the
+    // float reciprocal of their float sum.
+    const double q = 0.70710678118654752440084436210485, pi4 = 3.1415926535897932384626433832795 * 0.25;
+    const double rot[8][2] = {{1, 0}, {-q, -q}, {0, 1}, {q, -q}, {-1, 0}, {q, q}, {0, -1}, {-q, q}};
+    for (int p = 0; p < INTER_TAB_SIZE; p++) {
+        const float t = p * (1.f / INTER_TAB_SIZE);
+        const double a = -(t + 3) * pi4, sa = std::sin(a), ca = std::cos(a);
+        float* o = &w[(size_t)p * 8];
+        float total = 0;
+        for (int k = 0; k < 8; k++) {
+            const float d = t + 3 - k;
+            if (std::fabs(d) < 1e-6f) o[k] = 1e30f;
+            else {
+                const double y = -d * pi4;
+                o[k] = (float)((rot[k][0] * sa + rot[k][1] * ca) / (y * y));
+            }
+            total += o[k];
+        }
+        const float inv = 1.f / total;
+        for (int k = 0; k < 8; k++) o[k] *= inv;
+    }
+    return w;
 }
 
-// 2-D int16 table [32*32][ksize*ksize]; weights of every entry are corrected to sum to 32768 by
-// adjusting the largest (sum too small) or smallest (sum too large) tap of a central 2x2 group.
-static void build_itab(int ksize, int16_t* itab)
+// [32*32][ks*ks] int16.  The correction of an entry is applied right after the entry is quantised, while the
+// entries behind it are still zero: for the 2x2 table the window [lo, lo+2)^2 = [1, 3)^2 reaches past the entry
+// into that zero region (as in cv2's builder), where it can only ever fire at phase (0,0) -- the weight 32768
+// saturates to 32767 and the missing 1 lands on tap (1,1).
+static void build_itab(int ks, int16_t* itab)
 {
-    std::vector<float> t1(8 * INTER_TAB_SIZE);
-    const float scale = 1.f / INTER_TAB_SIZE;
-    for (int i = 0; i < INTER_TAB_SIZE; i++) {
-        if (ksize == 8) lanczos4_1d(i * scale, &t1[i * 8]);
-        else { t1[i * 2] = 1.f - i * scale; t1[i * 2 + 1] = i * scale; }
-    }
-    // The correction scans taps k1,k2 in [ksize/2, ksize/2+2) relative to the entry (cv2's table
-    // builder).  For the 2x2 table that window runs into the entries that follow, which are still zero
-    // when the entry is processed; it only ever fires at phase (0,0), where the weight 32768 saturates
-    // to 32767 and the missing 1 lands on the (ksize/2, ksize/2) tap.
-    const int glo = ksize / 2;
-    int16_t* const tab0 = itab;
-    const long total = (long)INTER_TAB_SIZE * INTER_TAB_SIZE * ksize * ksize;
-    for (long q = 0; q < total; q++) itab[q] = 0;
-    for (int i = 0; i < INTER_TAB_SIZE; i++)
-        for (int j = 0; j < INTER_TAB_SIZE; j++, itab += ksize * ksize) {
-            int isum = 0;
-            for (int k1 = 0; k1 < ksize; k1++) {
-                float vy = t1[i * ksize + k1];
-                for (int k2 = 0; k2 < ksize; k2++) {
-                    float v = vy * t1[j * ksize + k2];
-                    isum += itab[k1 * ksize + k2] = sat_short((int)lrintf(v * COEF_SCALE));
+    const std::vector<float> w = phase_weights(ks);
+    const int n = ks * ks, lo = ks == 8 ? g_fix_group_lo8 : ks / 2;
+    const long total = (long)INTER_TAB_SIZE * INTER_TAB_SIZE * n;
+    std::fill(itab, itab + total, (int16_t)0);
+    for (int py = 0; py < INTER_TAB_SIZE; py++)
+        for (int px = 0; px < INTER_TAB_SIZE; px++) {
+            int16_t* e = itab + ((long)py * INTER_TAB_SIZE + px) * n;
+            int sum = 0;
+            for (int ky = 0; ky < ks; ky++)
+                for (int kx = 0; kx < ks; kx++) {
+                    const float v = w[py * ks + ky] * w[px * ks + kx];
+                    sum += e[ky * ks + kx] = sat_short((int)lrintf(v * COEF_SCALE));
                 }
-            }
-            if (isum != COEF_SCALE) {
-                int diff = isum - COEF_SCALE;
-                int Mk1 = glo, Mk2 = glo, mk1 = glo, mk2 = glo;
-                const long room = total - (itab - tab0);
-                for (int k1 = glo; k1 < glo + 2; k1++)
-                    for (int k2 = glo; k2 < glo + 2; k2++) {
-                        if (k1 * ksize + k2 >= room) continue;
-                        if (itab[k1 * ksize + k2] < itab[mk1 * ksize + mk2]) mk1 = k1, mk2 = k2;
-                        else if (itab[k1 * ksize + k2] > itab[Mk1 * ksize + Mk2]) Mk1 = k1, Mk2 = k2;
-                    }
-                if (diff < 0) itab[Mk1 * ksize + Mk2] = (short)(itab[Mk1 * ksize + Mk2] - diff);
-                else itab[mk1 * ksize + mk2] = (short)(itab[mk1 * ksize + mk2] - diff);
-            }
+            const int excess = sum - COEF_SCALE;
+            if (excess == 0) continue;
+            // largest / smallest tap of the 2x2 group, first one wins on ties (scan order ky, kx)
+            const long room = total - (e - itab);
+            int big = lo * ks + lo, small = big;
+            for (int ky = lo; ky < lo + 2; ky++)
+                for (int kx = lo; kx < lo + 2; kx++) {
+                    const int i = ky * ks + kx;
+                    if (i >= room) continue;
+                    if (e[i] < e[small]) small = i;
+                    else if (e[i] > e[big]) big = i;
+                }
+            const int at = excess < 0 ? big : small;
+            e[at] = (short)(e[at] - excess);
         }
 }
 
@@ -283,6 +303,23 @@ static void inv3(const double m[9], double o[9])
 using namespace camd;
 
 extern "C" {
+
+int camd_set_global_option(int option, int value)
+{
+    if (option == CAMD_GOPT_LANCZOS_FIX_GROUP_LO && (value == 3 || value == 4)) {
+        std::lock_guard<std::mutex> lock(g_tab_mutex);
+        if (value != g_fix_group_lo8) {
+            g_fix_group_lo8 = value;
+            for (DevTables& t : g_tabs) {  // rebuilt on next use (the old copies may still be read by running kernels)
+                t.lanczos = nullptr;
+                t.bilinear = nullptr;
+            }
+        }
+        return CAMD_OK;
+    }
+    set_error("unknown global option %d / value %d", option, value);
+    return CAMD_ERR_BAD_ARG;
+}
 
 int camd_lanczos4_table_host(int16_t* tab)
 {

@@ -1006,8 +1006,11 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     const bool fused = K <= 11 && h->cost_path != CAMD_COST_SPLIT;
     MARK(ST_COST);
     if (fused) {
-        // waves per workgroup: one per 8 disparities, at least 4 (the staging needs up to 3 waves of lanes)
-        const int nw = g.Dp / COST_DL < 4 ? 4 : (g.Dp / COST_DL < 16 ? g.Dp / COST_DL : 16);
+        // waves per workgroup: one per 8 disparities, at least 4 (the staging needs up to 3 waves of lanes), at most
+        // 8 for RGB (three 8-wave workgroups share a CU at 74 VGPRs: 17.5 instead of 20.2 ms per 64 pairs; a 16-wave
+        // workgroup would have a CU to itself) and 16 for gray (fewer registers, and the staging per cell halves)
+        const int maxw = g.cn == 3 ? CAMD_COST_MAX_WAVES_RGB : CAMD_COST_MAX_WAVES_GRAY;
+        const int nw = g.Dp / COST_DL < 4 ? 4 : (g.Dp / COST_DL < maxw ? g.Dp / COST_DL : maxw);
         const int ndblk = div_up(g.Dp, nw * COST_DL);                   // disparity blocks of <= 128
         const int nstrips = div_up(g.W1, 64 - (K - 1));
         // row chunks: enough workgroups for ~32 rounds over the chip, but the saturating recurrence must start at row 0

@@ -30,8 +30,15 @@
 namespace camd {
 
 static constexpr int COST_DL = 8;  // disparities per lane
+// tunables (measured on MI355X)
+#ifndef CAMD_COST_MAX_WAVES_RGB
+#define CAMD_COST_MAX_WAVES_RGB 8    // waves per workgroup (x 8 disparities each)
+#endif
+#ifndef CAMD_COST_MAX_WAVES_GRAY
+#define CAMD_COST_MAX_WAVES_GRAY 16
+#endif
 #ifndef CAMD_COST_MIN_WAVES
-#define CAMD_COST_MIN_WAVES 4  // occupancy target (waves per SIMD) the register allocator works to
+#define CAMD_COST_MIN_WAVES 6        // occupancy target (waves per SIMD) the register allocator works to
 #endif
 
 // n applications of the one-lane wave shift (lane i <- lane i-1, lane 0 <- 0)

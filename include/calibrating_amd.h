@@ -148,6 +148,11 @@ int camd_init_undistort_rectify_map(const double A[9], const double* dist, int n
 /* device version of camd_undistort_maps_host: mapxy int16 [h][w][2], mapa uint16 [h][w] (device) */
 int camd_undistort_maps(const double K[9], const double* dist, int ndist, int w, int h, int16_t* mapxy,
                         uint16_t* mapa, void* stream);
+/* process-wide options.  CAMD_GOPT_LANCZOS_FIX_GROUP_LO: first index (3 or 4; default 4 = ksize/2) of the 2x2 tap
+ * group of a Lanczos-4 table entry that takes the weight-sum correction -- SURVEY.md A.10 uncertainty U15, the same
+ * switch the CPU oracle exposes (oracle_switches.lanczos_fix_group_lo), so that one flip moves both. */
+enum { CAMD_GOPT_LANCZOS_FIX_GROUP_LO = 0 };
+int camd_set_global_option(int option, int value);
 /* host, init time: the 32x32-phase int16 weight tables cv2.remap uses (1024*64 / 1024*4 entries) */
 int camd_lanczos4_table_host(int16_t* tab_host);
 int camd_bilinear_table_host(int16_t* tab_host);

@@ -59,14 +59,46 @@ def test_argument_validation_without_gpu():
     assert "numDisparities" in _native.last_error()
     m3 = _native.SgbmParams(numDisparities=16, mode=2)
     assert lib.camd_sgbm_create(ctypes.byref(m3), 64, 64, 1, 1, ctypes.byref(h)) == _native.CAMD_ERR_UNSUPPORTED
-    # host-side table builders work without a device and match the oracle
-    tab = np.empty((1024, 64), np.int16)
-    assert lib.camd_lanczos4_table_host(tab.ctypes.data) == 0
+
+
+def test_interpolation_tables_three_independent_builders():
+    """The fixed-point Lanczos-4 / bilinear tables of the product (csrc/remap.hip), of the oracle (oracle/remap_ref.c)
+    and of an independently written NumPy model (tests/np_interp_tables.py) agree bit for bit -- for both settings of
+    the U15 correction-group switch, which the product and the oracle share (one flip moves both)."""
     import oracle
-    assert np.array_equal(tab, oracle.lanczos4_itab())
-    tb = np.empty((1024, 4), np.int16)
-    assert lib.camd_bilinear_table_host(tb.ctypes.data) == 0
-    assert np.array_equal(tb, oracle.bilinear_itab())
+    import np_interp_tables as model
+    lib = _native.lib()
+
+    def product_tables():
+        tab, tb = np.empty((1024, 64), np.int16), np.empty((1024, 4), np.int16)
+        assert lib.camd_lanczos4_table_host(tab.ctypes.data) == 0
+        assert lib.camd_bilinear_table_host(tb.ctypes.data) == 0
+        return tab, tb
+
+    try:
+        seen = []
+        for lo in (4, 3):
+            assert lib.camd_set_global_option(0, lo) == 0
+            oracle.set_switches(lanczos_fix_group_lo=lo)
+            tab, tb = product_tables()
+            assert np.array_equal(tab, model.lanczos4_itab(lo)), "product vs NumPy model, group %d" % lo
+            assert np.array_equal(oracle.lanczos4_itab(), model.lanczos4_itab(lo)), "oracle vs NumPy model, group %d" % lo
+            assert np.array_equal(tb, model.bilinear_itab()) and np.array_equal(oracle.bilinear_itab(), tb)
+            sums = tab.astype(np.int64).sum(1)
+            assert (tb.astype(np.int64).sum(1) == 32768).all()
+            if lo == 4:
+                assert (sums == 32768).all()
+            else:
+                # evidence for U15 = 4: with the group {3,4} the phase-(0,0) entry would add the missing 1 to its
+                # centre tap, which already holds the saturated 32767 -> (short)32768 = -32768: integer-coordinate
+                # remaps would negate the image, which cv2 visibly does not do
+                assert sums[0] == -32768 and (sums[1:] == 32768).all()
+            seen.append(tab.copy())
+        assert not np.array_equal(seen[0], seen[1]), "the switch must change some entries"
+        assert lib.camd_set_global_option(0, 7) != 0 and lib.camd_set_global_option(99, 0) != 0
+    finally:
+        lib.camd_set_global_option(0, 4)
+        oracle.set_switches()
 
 
 def test_plugin_surface_matches_reference_names():

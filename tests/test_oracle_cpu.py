@@ -1,6 +1,6 @@
 """CPU tests of the oracle itself (no GPU): the sequential C restatement against the independent
 parallel-form NumPy model, analytic known answers, SciPy cross-checks for
-the median / connected components, and the committed golden fixtures."""
+the median / connected components (the committed golden fixtures: tests/test_golden_cpu.py)."""
 import os
 
 import numpy as np
@@ -218,22 +218,6 @@ def test_unrectify_matches_reference_expression(oracle):
     mx, my = xs.astype(np.float32), ys.astype(np.float32)
     got = oracle.unrectify_depth(depth, Mfull[2], mx, my)
     assert np.abs(got - want_z).max() < 1e-12
-
-
-def test_golden_fixtures(oracle):
-    """Oracle outputs frozen under tests/golden (made by tests/golden/make_golden.py)."""
-    path = os.path.join(GOLDEN, "sgbm_small.npz")
-    assert os.path.exists(path), "run python tests/golden/make_golden.py"
-    z = np.load(path)
-    n = int(z["n"])
-    for i in range(n):
-        p = {k: int(v) for k, v in zip(z["param_names"], z["params_%d" % i])}
-        got = oracle.sgbm_compute(z["left_%d" % i], z["right_%d" % i], **p)
-        assert np.array_equal(got, z["disp_%d" % i]), "golden case %d" % i
-    r = np.load(os.path.join(GOLDEN, "remap_small.npz"))
-    assert np.array_equal(oracle.remap_u8(r["src"], r["mapx"], r["mapy"], 4), r["lanczos4"])
-    assert np.array_equal(oracle.remap_u8(r["src"], r["mapx"], r["mapy"], 1), r["linear"])
-    assert np.array_equal(oracle.lanczos4_itab(), r["lanczos4_itab"])
 
 
 def test_oracle_refuses_undefined_narrow_case(oracle):
