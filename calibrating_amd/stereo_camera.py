@@ -204,7 +204,7 @@ class Stereo:
         if isinstance(path_or_np, str):
             from PIL import Image
             with Image.open(path_or_np) as im:
-                return np.asarray(im.convert("RGB"))
+                return np.array(im.convert("RGB"))
         return path_or_np
 
     @staticmethod

@@ -233,7 +233,7 @@ def run(backend, case):
             return dict(dst=cv2.resize(x["src"], hw[::-1], interpolation=cv2.INTER_LINEAR))
         if backend == "oracle":
             return dict(dst=oracle.resize_linear(x["src"], hw))
-        return dict(dst=_resize.resize(x["src"], hw))
+        return dict(dst=_resize.resize(torch.from_numpy(np.ascontiguousarray(x["src"])).cuda(), hw))
     if st == "post":
         nv, ms, md = int(x["new_val"]), int(x["max_size"]), int(x["max_diff"])
         if backend == "cv2":

@@ -1,0 +1,184 @@
+"""The rest of `Stereo.get_depth`'s contract (-m gpu): branches of the reference's orchestration
+(/root/reference/calibrating/stereo_camera.py:492-533) that the headline configs do not reach -- foreign
+MetaStereoMatching plugins (array or dict results, in-place `+= min_disparity`), rectified sizes that differ from
+the source size (xy_target / K_target), image-file inputs, and the U7 saturate / wrap switch of the cost volume."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import calibrating_amd as ca  # noqa: E402
+from calibrating_amd import synthetic  # noqa: E402
+
+from test_gpu_pipeline import DEPTH_TOL, _oracle_get_depth  # noqa: E402
+
+
+class _ForeignPlugin(ca.MetaStereoMatching):
+    """A matcher written against the reference's plugin surface only: NumPy RGB in, float32 disparity (or a dict
+    holding it) out.  Keeps what it saw and what it returned for the assertions."""
+
+    def __init__(self, cfg=None):
+        super().__init__(cfg)
+        self.returned = None
+
+    def __call__(self, img1, img2):
+        assert isinstance(img1, np.ndarray) and img1.dtype == np.uint8 and img1.ndim == 3 and img1.shape == img2.shape
+        self.seen = (img1.copy(), img2.copy())
+        h, w = img1.shape[:2]
+        disp = (5.0 + 20.0 * (np.mgrid[:h, :w][1] / w)).astype(np.float32)
+        disp[::7, ::5] = 0  # holes: depth must come out 0 there only when nothing is added back
+        self.returned = disp
+        if self.cfg and self.cfg.get("as_dict"):
+            return dict(disparity=disp, confidence=np.ones((h, w), np.float32) * 0.5, note="extra keys are merged")
+        return disp
+
+
+@pytest.mark.parametrize("as_dict", [False, True])
+@pytest.mark.parametrize("max_depth", [None, 3.5])
+def test_foreign_plugin_contract(oracle, as_dict, max_depth):
+    W, H = 320, 240
+    stereo = ca.Stereo.load(synthetic.rig(W, H))
+    plugin = _ForeignPlugin(dict(as_dict=as_dict))
+    stereo.set_stereo_matching(plugin, max_depth=max_depth)
+    img1, img2 = synthetic.scene_pair(11, W, H, 3)
+    got = stereo.get_depth(img1, img2)
+    # the plugin saw the rectified (and, with max_depth, translated) NumPy images
+    assert np.array_equal(plugin.seen[0], got["rectify_img1"]) and np.array_equal(plugin.seen[1], got["rectify_img2"])
+    # reference :510-513 -- `disparity += min_disparity` happens IN PLACE on the plugin's own array, then * mask
+    h, w = img1.shape[:2]
+    base = (5.0 + 20.0 * (np.mgrid[:h, :w][1] / w)).astype(np.float32)
+    base[::7, ::5] = 0
+    shift = stereo.min_disparity if max_depth else 0
+    assert stereo.translation_rectify_img == bool(max_depth)
+    assert np.array_equal(plugin.returned, base + np.float32(shift)), "in-place += visible on the plugin's array"
+    want_disp = stereo.rectify_valid_mask1 * (base + np.float32(shift))
+    assert np.array_equal(got["disparity"], want_disp)
+    with np.errstate(divide="ignore"):
+        want_depth = 1.0 * stereo.baseline * stereo.K[0, 0] / want_disp
+    want_depth[want_depth > stereo.get_max_depth()] = 0
+    want_depth[want_depth < 0] = 0
+    assert np.abs(got["rectify_depth"] - want_depth).max() <= DEPTH_TOL
+    if as_dict:
+        assert got["note"] == "extra keys are merged" and got["confidence"].shape == (H, W)
+    else:
+        assert "note" not in got
+    for k in ("unrectify_depth", "undistort_img1"):
+        assert k in got
+    assert set(stereo.get_depth(img1, img2, return_unrectify_depth=False)) >= {"rectify_img1", "rectify_depth", "disparity",
+                                                                              "rectify_img2"}
+
+
+@pytest.mark.parametrize("xy_target,K_target", [(0.5, 0.5), ((400, 260), 1), (None, 0.8), (1.25, 1)])
+def test_get_depth_with_resized_rectified_frame(oracle, xy_target, K_target):
+    """Rectified size != source size (reference stereo_camera.py:125-156: xy_target / K_target), single and batched."""
+    W, H = 480, 320
+    rig = synthetic.rig(W, H)
+    stereo = ca.Stereo(ca.Cam.load(rig["cam1"]), ca.Cam.load(rig["cam2"]), xy_target=xy_target, K_target=K_target,
+                       R=np.array(rig["R"]), t=np.array(rig["t"]))
+    Wt, Ht = stereo.xy
+    if isinstance(xy_target, float):
+        assert (Wt, Ht) == (int(round(W * xy_target)), int(round(H * xy_target)))
+    elif xy_target is not None:
+        assert (Wt, Ht) == tuple(xy_target)
+    cfg = dict(max_size=max(Wt, Ht), minDisparity=0, numDisparities=48, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+               uniquenessRatio=10, speckleWindowSize=60, speckleRange=2)
+    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=4.0)
+    img1, img2 = synthetic.scene_pair(13, W, H, 3)
+    got = stereo.get_depth(img1, img2)
+    assert got["rectify_img1"].shape == (Ht, Wt, 3) and got["disparity"].shape == (Ht, Wt)
+    assert got["unrectify_depth"].shape == (H, W) and got["undistort_img1"].shape == (H, W, 3)
+    ref = _oracle_get_depth(oracle, stereo, {k: v for k, v in cfg.items() if k != "max_size"}, img1, img2)
+    for k in ("rectify_img1", "rectify_img2", "undistort_img1", "disparity"):
+        assert np.array_equal(got[k], ref[k]), k
+    for k in ("rectify_depth", "unrectify_depth"):
+        assert np.array_equal(got[k] == 0, ref[k] == 0), k
+        assert np.abs(got[k] - ref[k]).max() <= DEPTH_TOL, k
+    # the batched form gates max_size on the RECTIFIED size, like get_depth, and returns the same numbers
+    gb = stereo.get_depth_batch(np.stack([img1, img1]), np.stack([img2, img2]))
+    for k in got:
+        assert np.array_equal(gb[k][1], got[k], equal_nan=True), k
+    small = ca.SemiGlobalBlockMatching(dict(cfg, max_size=max(Wt, Ht) - 1))
+    stereo.set_stereo_matching(small, max_depth=4.0)
+    with pytest.raises(ValueError, match="rectified image size"):
+        stereo.get_depth_batch(np.stack([img1]), np.stack([img2]))
+    assert stereo.get_depth(img1, img2)["disparity"].shape == (Ht, Wt)  # get_depth itself downsizes instead
+
+
+def test_get_depth_reads_image_files(tmp_path):
+    """`Stereo._get_img` accepts a path like the reference (stereo_camera.py:304-308)."""
+    from PIL import Image
+    W, H = 160, 120
+    stereo = ca.Stereo.load(synthetic.rig(W, H))
+    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(max_size=W, numDisparities=32, minDisparity=0, blockSize=5)),
+                               max_depth=3.0)
+    img1, img2 = synthetic.scene_pair(17, W, H, 3)
+    p1, p2 = str(tmp_path / "l.png"), str(tmp_path / "r.png")
+    Image.fromarray(img1).save(p1)
+    Image.fromarray(img2).save(p2)
+    a, b = stereo.get_depth(p1, p2), stereo.get_depth(img1, img2)
+    for k in b:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def _c_volume(matcher):
+    return matcher.debug_volume("C").cpu().numpy()
+
+
+def _sawtooth_pair(H, W):
+    """Opposite sawtooth ramps (slope +-16 per pixel, phase drifting with the row): every gradient plane of the left
+    image sits at its upper clip, of the right image at its lower clip, and the raw planes are far apart -- the
+    largest pixel costs images can produce."""
+    x, y = np.arange(W)[None, :], np.arange(H)[:, None]
+    ramp = ((x * 16 + y * 40) % 256).astype(np.uint8)
+    left = ramp[..., None].repeat(3, 2)
+    return left, 255 - left
+
+
+@pytest.mark.parametrize("saturate", [1, 0])
+@pytest.mark.parametrize("cost_path", [1, 2])
+@pytest.mark.parametrize("cap", [31, 63])
+def test_u7_saturate_switch_matches_oracle(oracle, saturate, cost_path, cap):
+    """Block 11 x RGB with a raised preFilterCap on opposite sawtooth ramps drives window sums past 32767 (a few
+    percent of the cells at cap 31, most at 63; at the default cap 0 even these images stay below 26000): the cost
+    volume must follow OpenCV's CV_SIMD saturation (default) or the scalar build's wrap, as the switch says, in the
+    fused kernel (cost_path 1) and in the split pair (2) alike."""
+    H, W, D = 36, 260, 96
+    left, right = _sawtooth_pair(H, W)
+    p = dict(minDisparity=0, numDisparities=D, blockSize=11, P1=968, P2=3872, disp12MaxDiff=1, uniquenessRatio=5,
+             preFilterCap=cap)
+    try:
+        oracle.set_switches(cost_saturate=saturate)
+        want = oracle.sgbm_cost_volume(left, right, **p)
+        m = ca.StereoSGBM_create(**p)
+        m.set_option("saturate", saturate).set_option("cost", cost_path)
+        disp = m.compute(left, right)
+        got = _c_volume(m)
+        assert np.array_equal(got, want), "C volume, saturate=%d: %d cells differ" % (saturate, (got != want).sum())
+        if saturate:
+            assert (want == 32767).any(), "the case must actually saturate"
+            assert want.min() >= 0
+            # with C inside [0, 32767] the aggregation stays in its exact regime: the disparity matches as well
+            assert np.array_equal(disp, oracle.sgbm_compute(left, right, **p))
+        else:
+            assert (want < 0).any(), "the case must actually wrap"
+    finally:
+        oracle.set_switches()
+
+
+def test_u7_modes_agree_without_overflow(oracle):
+    """Block 11 x RGB on black/white and checkerboard images (the reference's default block size): no window sum
+    reaches 32767, so saturate and wrap give the same disparity, equal to the oracle's."""
+    H, W, D = 40, 300, 96
+    p = dict(minDisparity=0, numDisparities=D, blockSize=11, P1=968, P2=3872, disp12MaxDiff=1, uniquenessRatio=5)
+    bw = np.zeros((H, W, 3), np.uint8)
+    bw[:, W // 2:] = 255
+    chk = ((np.add.outer(np.arange(H), np.arange(W)) & 1) * 255).astype(np.uint8)[..., None].repeat(3, 2)
+    for l, r in ((bw, 255 - bw), (chk, 255 - chk), (chk, bw)):
+        want = oracle.sgbm_compute(l, r, **p)
+        assert oracle.sgbm_cost_volume(l, r, **p).max() < 32767
+        for sat in (1, 0):
+            m = ca.StereoSGBM_create(**p)
+            m.set_option("saturate", sat)
+            assert np.array_equal(m.compute(l, r), want)
