@@ -96,13 +96,13 @@ def cpu_baseline(a, params):
     oracle.build()
     ncpu = os.cpu_count() or 1
     threads = ncpu
-    # bounded sample (~10-30 s of CPU work): full-width strips of half the rows (SGBM cost is linear in
-    # rows), two strips per thread; scaled back to whole pairs below
-    hs = max(a.height // 2, 16)
+    # bounded sample (~10-30 s of CPU work): full-width strips of a quarter of the rows (SGBM cost is linear in
+    # rows), one strip per thread; scaled back to whole pairs below
+    hs = max(a.height // 4, 16)
     if a.mode == "hh":  # the two-pass mode keeps two whole strip volumes per thread: bound the host memory (32 GB)
         vol = 2 * 2 * hs * max(a.width - a.disparities, 1) * a.disparities
         threads = max(1, min(threads, int(32e9 // vol)))
-    n = a.cpu_pairs or 2 * threads
+    n = a.cpu_pairs or threads
     base_l, base_r = synthetic.rectified_pair(seed=1234, H=hs, W=a.width, D=a.disparities, cn=a.channels)
     L = np.stack([np.roll(base_l, 17 * i, axis=0) for i in range(n)])  # distinct strips: vertical rolls
     R = np.stack([np.roll(base_r, 17 * i, axis=0) for i in range(n)])

@@ -635,7 +635,8 @@ struct camd_sgbm {
     uint32_t* err_host;   // pinned mirror of *err, refreshed by an async copy after every band-path compute
     int16_t* d1;
     uint32_t epoch;
-    uint16_t* Smulti;     // concurrent-direction path: npaths volumes per pair, allocated on first use
+    uint16_t* Smulti;     // concurrent-direction path: npaths volumes for smulti_cap pairs (allocated in create / set_option)
+    int smulti_cap;
     int last_batch;
     bool profiling;
     hipEvent_t ev[camd::ST_COUNT + 1];
@@ -703,6 +704,20 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// work of one pair in units of one 1080p / D=128 volume: the AUTO path rule and its workspace follow it
+static double pair_work(const Geom& g) { return ((double)g.H * g.W1 * g.Dp) / (1080.0 * 1792.0 * 128.0); }
+static double auto_concurrent_limit(const Geom& g) { return g.mode == CAMD_MODE_HH ? 8.0 : 4.0; }
+// largest batch the AUTO rule sends down the concurrent-direction path (it needs npaths volumes per pair)
+static int auto_concurrent_pairs(const Geom& g, bool band_ok, int max_batch)
+{
+    int cap = max_batch < CAMD_MULTI_MAX_BATCH ? max_batch : CAMD_MULTI_MAX_BATCH;
+    if (band_ok) {
+        const int n = (int)(auto_concurrent_limit(g) / pair_work(g));
+        cap = n < cap ? n : cap;
+    }
+    return cap;
+}
 
 // ndirs directions in one launch (ndirs > 1 only with FIRST: each direction writes its own volume)
 template <bool FIRST>
@@ -823,6 +838,7 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
         total += (size_t)max_batch * nb * (band_erec_stride(g.W1, g.lanes, g.nv) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
         total += (size_t)max_batch * height * width * 6 + 8;
     }
+    total += (size_t)g.npaths * auto_concurrent_pairs(g, band_ok, max_batch) * vol;  // per-direction volumes (latency path)
     return total;
 }
 
@@ -877,6 +893,9 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         if (e == hipSuccess) e = hipHostMalloc((void**)&h->err_host, 4, hipHostMallocDefault);
         if (e == hipSuccess) *h->err_host = 0;
     }
+    h->smulti_cap = w1 > 0 ? auto_concurrent_pairs(g, h->band_ok, max_batch) : 0;
+    if (e == hipSuccess && h->smulti_cap > 0)
+        e = hipMalloc((void**)&h->Smulti, (size_t)g.npaths * h->smulti_cap * h->vol_elems * 2);
     if (e != hipSuccess) {
         set_error("workspace allocation failed: %s", hipGetErrorString(e));
         camd_sgbm_destroy(h);
@@ -913,7 +932,27 @@ int camd_sgbm_query(const camd_sgbm* h, int* width1, int* D, int* Dp, int* minX1
 int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
 {
     if (!h) { set_error("handle is NULL"); return CAMD_ERR_BAD_ARG; }
-    if (option == CAMD_OPT_PATH && value >= CAMD_PATH_AUTO && value <= CAMD_PATH_CONCURRENT) h->path = value;
+    if (option == CAMD_OPT_PATH && value >= CAMD_PATH_AUTO && value <= CAMD_PATH_CONCURRENT) {
+        if (value == CAMD_PATH_CONCURRENT && h->g.W1 > 0) {
+            // an explicit request may exceed what AUTO would use: grow the per-direction volumes here (an init-time
+            // call), never inside the stream-ordered compute
+            const int want = h->max_batch < CAMD_MULTI_MAX_BATCH ? h->max_batch : CAMD_MULTI_MAX_BATCH;
+            if (want > h->smulti_cap) {
+                CAMD_HIP(hipDeviceSynchronize());
+                (void)hipFree(h->Smulti);
+                h->Smulti = nullptr;
+                h->smulti_cap = 0;
+                hipError_t e = hipMalloc((void**)&h->Smulti, (size_t)h->g.npaths * want * h->vol_elems * 2);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    set_error("no memory for %d x %d per-direction volumes", h->g.npaths, want);
+                    return CAMD_ERR_NOMEM;
+                }
+                h->smulti_cap = want;
+            }
+        }
+        h->path = value;
+    }
     else if (option == CAMD_OPT_KEEP_S) h->keep_S = value != 0;
     else if (option == CAMD_OPT_COST && value >= CAMD_COST_AUTO && value <= CAMD_COST_SPLIT) h->cost_path = value;
     else if (option == CAMD_OPT_SATURATE) h->saturate = value != 0;
@@ -1100,22 +1139,16 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     // per call for 5 paths (3.1 / 2.4 / 2.0 against 6.8 / 3.7 / 2.2 through the band passes) and up to 8 pairs
     // for 8 paths (3.6 ... 2.6 against 13.1 ... 2.9); from there on the band passes take over (1.36 / 1.87 at 16
     // pairs, 0.98 / 1.14 at 64).
-    const int mcap = h->max_batch < CAMD_MULTI_MAX_BATCH ? h->max_batch : CAMD_MULTI_MAX_BATCH;
+    const int mcap = h->smulti_cap;
     int path = h->path;
     if (path == CAMD_PATH_AUTO) {
         // the thresholds scale with the work per pair (in units of one 1080p / D=128 volume)
-        const double work = (double)batch * ((double)g.H * g.W1 * g.Dp) / (1080.0 * 1792.0 * 128.0);
-        if (work <= (g.mode == CAMD_MODE_HH ? 8.0 : 4.0) || !h->band_ok) path = CAMD_PATH_CONCURRENT;
+        if (batch * pair_work(g) <= auto_concurrent_limit(g) || !h->band_ok) path = CAMD_PATH_CONCURRENT;
         else path = CAMD_PATH_BAND;
     }
     if (path == CAMD_PATH_BAND && !h->band_ok) path = CAMD_PATH_SCAN;
-    if (path == CAMD_PATH_CONCURRENT) {
-        if (batch > mcap) path = h->band_ok && h->path == CAMD_PATH_AUTO ? CAMD_PATH_BAND : CAMD_PATH_SCAN;
-        else if (!h->Smulti) {
-            hipError_t e = hipMalloc((void**)&h->Smulti, (size_t)g.npaths * mcap * h->vol_elems * 2);
-            if (e != hipSuccess) { (void)hipGetLastError(); path = h->band_ok ? CAMD_PATH_BAND : CAMD_PATH_SCAN; }
-        }
-    }
+    // the per-direction volumes were sized in create / set_option: a larger batch takes the next best path
+    if (path == CAMD_PATH_CONCURRENT && batch > mcap) path = h->band_ok ? CAMD_PATH_BAND : CAMD_PATH_SCAN;
     const bool band = path == CAMD_PATH_BAND;
     const bool multi = path == CAMD_PATH_CONCURRENT;
     const size_t dir_stride = (size_t)mcap * h->vol_elems;

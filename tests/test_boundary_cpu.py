@@ -49,9 +49,13 @@ def test_argument_validation_without_gpu():
     import ctypes
     lib = _native.lib()
     p = _native.SgbmParams(numDisparities=128, blockSize=5, P1=200, P2=800)
-    # C2 workspace: two 495 MB volumes + planes + raw disparity per pair
+    # C2 workspace: C and S (495 MB each) + the five per-direction volumes of the one-pair latency path + edge
+    # records, keys, raw disparity; with 64 pairs per call the latency path holds at most 4 pairs' worth
+    V = 1080 * 1792 * 128 * 2
     ws = lib.camd_sgbm_workspace_bytes(ctypes.byref(p), 1920, 1080, 1, 1)
-    assert 2 * 1080 * 1792 * 128 * 2 < ws < 2.4 * 1080 * 1792 * 128 * 2
+    assert 7 * V < ws < 7.4 * V
+    ws64 = lib.camd_sgbm_workspace_bytes(ctypes.byref(p), 1920, 1080, 1, 64)
+    assert (2 * 64 + 5 * 4) * V < ws64 < (2.4 * 64 + 5 * 4) * V
     assert lib.camd_sgbm_workspace_bytes(ctypes.byref(p), 1920, 1080, 2, 1) == 0  # 2 channels: cv2 error too
     bad = _native.SgbmParams(numDisparities=0)
     h = ctypes.c_void_p()
