@@ -438,9 +438,9 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
                 uint32_t mn = SENT_PK;
 #pragma unroll
                 for (int k = 0; k < NR; k++) {
+                    // C + min(Lp, t, delta) - delta  ==  C - max(delta - min(Lp, t), 0)   (mod 2^16): one op less
                     uint32_t t = pk_add_u16(pk_min_u16(m[k], m[k + 1]), P1pk);
-                    uint32_t a = pk_min_u16(pk_min_u16(Lp[k], t), delta);
-                    uint32_t l = pk_sub_u16(pk_add_u16(c[k], a), delta);
+                    uint32_t l = pk_sub_u16(c[k], pk_subsat_u16(delta, pk_min_u16(Lp[k], t)));
                     if (PAD) l = (l & keep[k]) | sent[k];
                     L[k] = l;
                     mn = pk_min_u16(mn, l);

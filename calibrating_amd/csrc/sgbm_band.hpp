@@ -39,6 +39,9 @@ namespace camd {
 static constexpr int BAND_THREADS = 448;                 // compute threads
 static constexpr int BAND_BLOCK = BAND_THREADS + 64;     // + one helper wave
 static constexpr int BAND_RING = 4;                      // C/S prefetch ring (xi .. xi+3)
+#ifndef BAND_RING_ROWS
+#define BAND_RING_ROWS 4                                 // ... of the row-parallel (!FULL) pass
+#endif
 static constexpr int BAND_CHUNK = 16;                    // columns per edge flag
 static constexpr uint32_t BAND_SPIN_LIMIT = 1u << 20;    // ~0.1 s of s_sleep polling, then give up
 
@@ -78,9 +81,9 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&Lp)[NR], uint32_t 
     uint32_t mn = SENT_PK;
 #pragma unroll
     for (int k = 0; k < NR; k++) {
+        // C + min(Lp, Lp[d-1] + P1, Lp[d+1] + P1, delta) - delta  ==  C - max(delta - min(Lp, ...), 0)   (mod 2^16)
         uint32_t t = pk_add_u16(pk_min_u16(m[k], m[k + 1]), P1pk);
-        uint32_t a = pk_min_u16(pk_min_u16(Lp[k], t), delta);
-        uint32_t l = pk_sub_u16(pk_add_u16(c[k], a), delta);
+        uint32_t l = pk_sub_u16(c[k], pk_subsat_u16(delta, pk_min_u16(Lp[k], t)));
         if (PAD) l = (l & keep[k]) | sent[k];  // d >= D carries MAX_COST
         L[k] = l;
         mn = pk_min_u16(mn, l);
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
     constexpr int R = BAND_THREADS / LANES;
     constexpr int EVEC = 6 * NV;     // u64 per lane per column: V (2NV), Dg (2NV), A (2NV)
     constexpr int CPB = 64 / LANES;  // columns the helper wave fetches per batch
-    constexpr int RING = BAND_RING;
+    constexpr int RING = FULL ? BAND_RING : BAND_RING_ROWS;
     constexpr int SK = FULL ? 2 : 0;
     constexpr int XN = FULL ? BAND_THREADS * NV : 1, EN = FULL ? 64 * NV : 1;
 
