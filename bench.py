@@ -327,9 +327,8 @@ def main():
                            "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": (tr * nb) if tr is not None else None}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms_per_launch"]) if kernels else None
-        traffic_total = None
-        if pmc and kernels and all(v["traffic"] is not None for k, v in kernels.items() if k in ("cost", "hsum", "vsum", "scan", "scan_last")):
-            traffic_total = sum(v["traffic"] for v in kernels.values() if v["traffic"] is not None)
+        # whole-step traffic = every kernel of the committed PMC profile (incl. the small init / check kernels)
+        traffic_total = sum(v["hbm_bytes_per_pair"] for v in pmc["kernels"].values()) * nb if pmc else None
         achieved = b_alg * nb / (gpu_ms_step * 1e-3) / 1e9
         line = {
             "metric": "stereo pairs/s at 1920x1080 numDisparities=128",
