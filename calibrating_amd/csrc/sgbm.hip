@@ -654,8 +654,8 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
     }
     if (p->numDisparities <= 0) { set_error("numDisparities must be > 0"); return CAMD_ERR_BAD_ARG; }
     if (p->mode != CAMD_MODE_SGBM && p->mode != CAMD_MODE_HH && p->mode != CAMD_MODE_HH4) {
-        set_error("mode %d not implemented (MODE_SGBM=0, MODE_HH=1, MODE_HH4=3; MODE_SGBM_3WAY is a tiled variant "
-                  "without a thread-count independent answer)", p->mode);
+        set_error("mode %d not implemented (MODE_SGBM=0, MODE_HH=1, MODE_HH4=3; MODE_SGBM_3WAY=2, cv2's variant of four "
+                  "row stripes x three directions, is not: see INTEGRATION.md)", p->mode);
         return CAMD_ERR_UNSUPPORTED;
     }
     memset(g, 0, sizeof(*g));

@@ -51,7 +51,8 @@ typedef struct camd_sgbm_params {
     int speckleWindowSize;
     int speckleRange;
     int mode; /* CAMD_MODE_SGBM = 0 (5 paths; the reference's call), CAMD_MODE_HH = 1 (8 paths),
-                 CAMD_MODE_HH4 = 3 (4 paths); cv2's MODE_SGBM_3WAY (2) is not implemented */
+                 CAMD_MODE_HH4 = 3 (4 paths); cv2's MODE_SGBM_3WAY (2: four row stripes x three
+                 directions) is not implemented */
 } camd_sgbm_params;
 enum { CAMD_MODE_SGBM = 0, CAMD_MODE_HH = 1, CAMD_MODE_HH4 = 3 };
 
