@@ -51,3 +51,49 @@ def test_c5_vga_get_depth_vs_oracle(oracle):
                                             1.0 * stereo.baseline * stereo.K[0, 0], 3.5)
     assert np.array_equal(res["disparity"], disparity)
     assert np.abs(res["rectify_depth"] - depth).max() <= 1e-4
+
+
+def test_c3_sharding_invariance():
+    """Config C3 (512 pairs sharded over 8 GPUs) at reduced size: a pair's disparity does not depend on which other
+    pairs share its launch, so rank r computing shard [lo, hi) of the global list (parallel_pairs.shard_range) gives
+    exactly the rows of the one-launch result -- the property the no-collective data path rests on."""
+    from calibrating_amd.parallel_pairs import owner_of, shard_range
+    n, world = 20, 8
+    dev = torch.device("cuda", 0)
+    P = dict(minDisparity=0, numDisparities=128, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1, uniquenessRatio=10)
+    L, R = synthetic.rectified_batch_torch(1234, n, 96, 640, 128, 3, dev)
+    whole = ca.StereoSGBM_create(**P).compute(L, R)
+    covered = []
+    for rank in range(world):
+        lo, hi = shard_range(n, world, rank)
+        covered += list(range(lo, hi))
+        assert all(owner_of(i, n, world) == rank for i in range(lo, hi))
+        if hi > lo:
+            part = ca.StereoSGBM_create(**P).compute(L[lo:hi], R[lo:hi])
+            assert torch.equal(part, whole[lo:hi]), rank
+    assert covered == list(range(n))
+    assert [shard_range(512, 8, r) for r in range(8)] == [(64 * r, 64 * r + 64) for r in range(8)]
+
+
+def test_rccl_path_with_one_forced_rank():
+    """bench.py's distributed branch on the GPU under torch.distributed.run with ONE rank: init_process_group("nccl")
+    (= RCCL), table broadcast, Stereo.install_tables, barrier-bracketed timing, all_gather of the results and the
+    cross-rank checksum agreement -- everything the multi-GPU run does except having a second device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CAMD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
+           "--batch", "8", "--width", "640", "--height", "360", "--no-also", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["rccl"]["backend"].startswith("nccl") and d["rccl"]["ranks_agree"] is True
+    assert d["rccl"]["table_bytes"] == 4 * 4 * 640 * 360 + 640 * 360
+    assert d["value"] > 0 and d["rccl"]["per_rank"][0]["pairs"] == 16
