@@ -85,6 +85,11 @@ static inline size_t cost_lds_bytes(int cn, int nwaves)
     return (size_t)2 * (nr + nl) * es * 4;
 }
 
+// Only one dword of an entry's third quad is used; left alone the compiler narrows that read to ds_read_b32, whose 32
+// lanes at a 48-byte stride collide four ways on the LDS banks, while the full ds_read_b128 is conflict-free
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#define KEEP_B128(q) asm volatile("" ::"v"(q))
+
 template <int CN, int K, bool SAT>
 __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     constexpr int NP = DL / 2;            // packed cost registers per lane
     constexpr int SW2 = K / 2;
     constexpr int XS = 64 - (K - 1);      // output columns per strip
-    extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
+    extern __shared__ uint4 cs_lds[];  // everything in LDS is addressed in 16-byte quads: b128 reads and writes
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6, DW = NW * DL;
     const int tid = threadIdx.x;
@@ -110,8 +115,8 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     const int lcol0 = cmin + g.minX1;                                 // image column of left entry 0
     const int rcol0 = cmin + g.minX1 - g.minD - (db + DW - 1);        // image column of right entry 0
     const int NRmax = 64 + DW - 1, NLmax = 64;
-    const int esz = (NRmax + NLmax) * ES;
-    uint32_t* const Ebuf = cs_lds;  // [2][esz]: right entries, then left entries
+    const int esz = (NRmax + NLmax) * EV;  // quads per buffer
+    uint4* const Ebuf = cs_lds;            // [2][esz]: right entries, then left entries
 
     const uint8_t* imgL = left + (size_t)pair * image_stride;
     const uint8_t* imgR = right + (size_t)pair * image_stride;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     const bool st_last = CN == 3 && st_ccol == g.W - 1;
     const uint8_t* st_ptr = (st_img == 1 ? imgL : imgR) + (size_t)st_ccol * CN - (st_last ? 1 : 0);
     const uint32_t st_shift = st_last ? 8u : 0u;
-    uint32_t* const st_dst = Ebuf + (st_img == 1 ? NRmax * ES : 0) + st_k * ES;  // + buffer * esz
+    uint4* const st_dst = Ebuf + (st_img == 1 ? NRmax * EV : 0) + st_k * EV;  // + buffer * esz
 
     uint32_t rowA = 0, rowB = 0, rowC = 0;  // the three image rows of the column being staged (in flight)
     auto fetch_rows = [&](int y) {
@@ -201,13 +206,13 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
                 hi[ch] = pk_max_u16(pk_max_u16(ul, ur), u[ch]);
             }
             if (st_store) {
-                uint4* d4 = reinterpret_cast<uint4*>(st_dst + buf * esz);
+                u32x4_t* d4 = reinterpret_cast<u32x4_t*>(st_dst + buf * esz);
                 if (CN == 1) {
-                    d4[0] = make_uint4(u[0], lo[0], hi[0], 0u);
+                    d4[0] = u32x4_t{u[0], lo[0], hi[0], 0u};
                 } else {
-                    d4[0] = make_uint4(u[0], lo[0], hi[0], u[1 % CN]);
-                    d4[1] = make_uint4(lo[1 % CN], hi[1 % CN], u[2 % CN], lo[2 % CN]);
-                    d4[2] = make_uint4(hi[2 % CN], 0u, 0u, 0u);
+                    d4[0] = u32x4_t{u[0], lo[0], hi[0], u[1 % CN]};
+                    d4[1] = u32x4_t{lo[1 % CN], hi[1 % CN], u[2 % CN], lo[2 % CN]};
+                    d4[2] = u32x4_t{hi[2 % CN], 0u, 0u, 0u};
                 }
             }
         }
@@ -249,15 +254,16 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
             const int r = r0 + u;
             if (r < nsteps) {  // uniform
 
-                const uint4* E4 = reinterpret_cast<const uint4*>(Ebuf + (r & 1) * esz);
+                const uint4* E4 = Ebuf + (r & 1) * esz;
                 uint32_t U[CN], U0[CN], U1[CN];
                 {
-                    const uint4* q = E4 + eoff_l;
+                    const u32x4_t* q = reinterpret_cast<const u32x4_t*>(E4 + eoff_l);
                     if (CN == 1) {
-                        const uint4 a = q[0];
+                        const u32x4_t a = q[0];
                         U[0] = a.x; U0[0] = a.y; U1[0] = a.z;
                     } else {
-                        const uint4 a = q[0], b = q[1], c = q[2];
+                        const u32x4_t a = q[0], b = q[1], c = q[2];
+                        KEEP_B128(c);
                         U[0] = a.x; U0[0] = a.y; U1[0] = a.z;
                         U[1 % CN] = a.w; U0[1 % CN] = b.x; U1[1 % CN] = b.y;
                         U[2 % CN] = b.z; U0[2 % CN] = b.w; U1[2 % CN] = c.x;
@@ -266,13 +272,14 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
                 uint32_t cost[DL];
 #pragma unroll
                 for (int j = 0; j < DL; j++) {
-                    const uint4* q = E4 + eoff_r + (DL - 1 - j) * EV;
+                    const u32x4_t* q = reinterpret_cast<const u32x4_t*>(E4 + eoff_r + (DL - 1 - j) * EV);
                     uint32_t V[CN], V0[CN], V1[CN];
                     if (CN == 1) {
-                        const uint4 a = q[0];
+                        const u32x4_t a = q[0];
                         V[0] = a.x; V0[0] = a.y; V1[0] = a.z;
                     } else {
-                        const uint4 a = q[0], b = q[1], c = q[2];
+                        const u32x4_t a = q[0], b = q[1], c = q[2];
+                        KEEP_B128(c);
                         V[0] = a.x; V0[0] = a.y; V1[0] = a.z;
                         V[1 % CN] = a.w; V0[1 % CN] = b.x; V1[1 % CN] = b.y;
                         V[2 % CN] = b.z; V0[2 % CN] = b.w; V1[2 % CN] = c.x;
