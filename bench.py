@@ -160,7 +160,7 @@ def pipelined_steps(matchers, streams, lefts, rights, outs, steps, warmup, distr
     return timed_steps(step, steps, warmup, torch.cuda.synchronize, distributed)
 
 
-def pcie_inclusive(matcher, left, right, out, steps):
+def pcie_inclusive(matcher, left, right, out, steps, streams=()):
     """pairs/s when every step's inputs come from (pinned) host memory and its disparities go back to it:
     H2D of step k+1 and D2H of step k-1 overlap the compute of step k on three streams, two device buffers."""
     import torch
@@ -170,7 +170,10 @@ def pcie_inclusive(matcher, left, right, out, steps):
     dl = [left, torch.empty_like(left)]
     dr = [right, torch.empty_like(right)]
     do = [out, torch.empty_like(out)]
-    s_in, s_out, s_cmp = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
+    # the copy streams REUSE the side streams of the timed region where they exist: HIP maps streams onto a handful of
+    # hardware queues, and a fifth live stream would share one with (and serialise against) the compute stream
+    pool = list(streams) + [torch.cuda.Stream() for _ in range(max(0, 2 - len(streams)))]
+    s_in, s_out, s_cmp = pool[0], pool[1], torch.cuda.current_stream()
     ev_in = [torch.cuda.Event() for _ in range(2)]
     ev_cmp = [torch.cuda.Event() for _ in range(2)]
     ev_out = [torch.cuda.Event() for _ in range(2)]
@@ -203,6 +206,27 @@ def pcie_inclusive(matcher, left, right, out, steps):
     return dict(pairs_per_s=nb * steps / dt, host_bytes_per_pair=bytes_per_pair,
                 host_link_GBs=bytes_per_pair * nb * steps / dt / 1e9,
                 note="pinned host buffers, H2D + compute + D2H overlapped on 3 streams, %d steps of %d pairs" % (steps, nb))
+
+
+def bind_near_gpu(index):
+    """Pin this process to the CPUs of the GPU's NUMA node (sysfs local_cpulist of its PCI function): pinned host
+    buffers then come from the memory next to the GPU's PCIe root, and with N ranks every rank stays beside its own
+    GPU.  Returns the cpulist string, or None when sysfs does not tell."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        cpulist = open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip()
+        cpus = set()
+        for part in cpulist.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return cpulist
+    except Exception:
+        pass
+    return None
 
 
 def self_launch(a):
@@ -239,6 +263,7 @@ def main():
         sys.exit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cpus_near_gpu = bind_near_gpu(local_rank)
     # CAMD_BENCH_FORCE_DIST=1 exercises the RCCL path (init, table broadcast, barrier, reductions) with a
     # single rank, e.g. under `python -m torch.distributed.run --nproc-per-node 1`
     distributed = world > 1 or (os.environ.get("CAMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
@@ -286,7 +311,8 @@ def main():
     agg = aggregate(nb * a.steps, dt, checksum, dev, distributed)
     value = agg["total_pairs"] / agg["seconds"]
     single_stream = nb * kprof / dt1
-    del matchers[1:], lefts[1:], rights[1:], outs[1:]
+    del matchers[1:], lefts[1:], rights[1:], outs[1:], m, l, r  # (the loop variables hold the last set alive)
+    torch.cuda.empty_cache()  # (the host-link rate measured below drops when much more HBM is allocated)
 
     rccl = None
     if distributed:
@@ -316,7 +342,10 @@ def main():
         k2 = max(3, min(a.steps, 10))
         also["note"] = "every figure in `also` is measured with ONE batch in flight on one stream"
         also["single_stream_pairs_per_s"] = single_stream
-        also["pcie_inclusive"] = pcie_inclusive(matcher, left, right, out, k2)
+        if os.environ.get("CAMD_BENCH_DEBUG"):
+            free, total = torch.cuda.mem_get_info()
+            sys.stderr.write("before pcie_inclusive: %.1f GB of %.1f GB free\n" % (free / 1e9, total / 1e9))
+        also["pcie_inclusive"] = pcie_inclusive(matcher, left, right, out, k2, streams)
         del matcher
         matchers.clear()
         # the other aggregation mode on the same inputs, and the gray variant of the headline mode
@@ -382,7 +411,7 @@ def main():
                                    % (a.width, a.height, "RGB" if a.channels == 3 else "gray", a.disparities,
                                       a.block, "MODE_HH(8 paths)" if a.mode == "hh" else "MODE_SGBM(5 paths)"),
                        "pairs_per_gpu_per_step": a.batch, "global_pairs_per_step": world * a.batch,
-                       "batches_in_flight_per_gpu": nfl,
+                       "batches_in_flight_per_gpu": nfl, "host_cpus_bound": cpus_near_gpu,
                        "parallelism": "pairs sharded over %d GPU(s), no data-path collective" % world},
             # Headline = SURVEY section 8(d): B_alg x pairs per step / time of one step in the timed region, against
             # the 8 TB/s HBM peak.  `kernels` / `dominant_kernel` characterise every kernel ALONE on the GPU (hipEvents
