@@ -8,9 +8,9 @@ GPU, computing does.
 """
 from .__info__ import __version__
 from .camera import Cam
-from .sgbm import MODE_HH, MODE_HH4, MODE_SGBM, StereoSGBM, StereoSGBM_create
+from .sgbm import MODE_HH, MODE_HH4, MODE_SGBM, MODE_SGBM_3WAY, StereoSGBM, StereoSGBM_create
 from .stereo_matching import MetaStereoMatching, SemiGlobalBlockMatching
 from .stereo_camera import Stereo
 
 __all__ = ["Cam", "Stereo", "MetaStereoMatching", "SemiGlobalBlockMatching", "StereoSGBM",
-           "StereoSGBM_create", "MODE_SGBM", "MODE_HH", "MODE_HH4", "__version__"]
+           "StereoSGBM_create", "MODE_SGBM", "MODE_HH", "MODE_SGBM_3WAY", "MODE_HH4", "__version__"]

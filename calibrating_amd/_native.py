@@ -24,7 +24,7 @@ CAMD_ERR_NOMEM = -5
 
 MODE_SGBM = 0
 MODE_HH = 1
-MODE_SGBM_3WAY = 2  # not implemented (cv2's four-stripe, three-direction variant)
+MODE_SGBM_3WAY = 2  # cv2's four-stripe, three-direction variant
 MODE_HH4 = 3
 INTER_NEAREST = 0
 INTER_LINEAR = 1

@@ -131,6 +131,15 @@ __device__ __forceinline__ uint32_t group_min_u32(uint32_t v)
     return v;
 }
 template <int LANES>
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t v)
+{
+    if (LANES >= 2) v = max(v, dpp_mov<DPP_QUAD_XOR1>(v, v));
+    if (LANES >= 4) v = max(v, dpp_mov<DPP_QUAD_XOR2>(v, v));
+    if (LANES >= 8) v = max(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v, v));
+    if (LANES >= 16) v = max(v, dpp_mov<DPP_ROW_MIRROR>(v, v));
+    return v;
+}
+template <int LANES>
 __device__ __forceinline__ uint32_t group_or_u32(uint32_t v)
 {
     if (LANES >= 2) v |= dpp_mov<DPP_QUAD_XOR1>(v, v);

@@ -1,5 +1,5 @@
 // sgbm.hip -- Semi-Global Block Matching for gfx950 (MI355X), bit-exact with cv2.StereoSGBM
-// (modes MODE_SGBM and MODE_HH) at equal parameters.
+// (modes MODE_SGBM, MODE_HH, MODE_HH4 and MODE_SGBM_3WAY) at equal parameters.
 //
 // Replaces the cv2.StereoSGBM_create(...).compute(left, right) call of the reference
 // (/root/reference/calibrating/stereo_matching.py:48-58,63).  Not a port of OpenCV's row-incremental
@@ -475,7 +475,7 @@ static constexpr uint32_t KEY_INIT = 0x7fff0000u;
 template <int LANES, int NV>
 __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, int16_t* __restrict__ disp,
                                              size_t disp_pitch_e, size_t disp_stride_e, Geom g,
-                                             size_t vol_stride, int nvol, size_t dir_stride)
+                                             size_t vol_stride, int nvol, size_t dir_stride, int tie_lanes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);          // [W]
@@ -522,7 +522,40 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
             if (d0 + 1 < g.D) key = min(key, (hi << 16) | (uint32_t)(d0 + 1));
         }
         key = group_min_u32<LANES>(key);
-        const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
+        int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
+        if (tie_lanes == 8) {
+            // MODE_SGBM_3WAY as OpenCV's CV_SIMD build decides ties (oracle/sgbm_ref.c way3_winner): the disparities
+            // below E are scanned 8 at a time, every one of the 8 lane slots keeps the LAST d that attains its minimum,
+            // the winner is the smallest of those positions among the slots that hold the global minimum; the scalar
+            // tail [E, D) only wins with a strictly smaller total.  A lane owns whole groups of 8 consecutive d here, so
+            // element e of every group is slot e.
+            const int E = (g.D % 8 == 0) ? g.D : 8 * ((g.D - 1) / 8);
+            uint32_t m1 = 0xffffu, ktail = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < NR; k++) {
+                const int d0 = dbase + 2 * k;
+                const uint32_t lo = s[k] & 0xffffu, hi = s[k] >> 16;
+                if (d0 < E) m1 = min(m1, lo); else if (d0 < g.D) ktail = min(ktail, (lo << 16) | (uint32_t)d0);
+                if (d0 + 1 < E) m1 = min(m1, hi); else if (d0 + 1 < g.D) ktail = min(ktail, (hi << 16) | (uint32_t)(d0 + 1));
+            }
+            m1 = group_min_u32<LANES>(m1);
+            ktail = group_min_u32<LANES>(ktail);
+            uint32_t pos = 0xffffffffu;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                uint32_t last = 0;  // 1 + the largest d of slot e (in this lane) whose total is the minimum
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const int k = 4 * v + e / 2, d = dbase + 8 * v + e;
+                    const uint32_t val = (e & 1) ? (s[k] >> 16) : (s[k] & 0xffffu);
+                    if (d < E && val == m1) last = (uint32_t)d + 1;
+                }
+                last = group_max_u32<LANES>(last);
+                if (last) pos = min(pos, last - 1);
+            }
+            if (E > 0 && (ktail >> 16) >= m1) { minS = (int)m1; best = (int)pos; }
+            else { minS = (int)(ktail >> 16); best = (int)(ktail & 0xffffu); }
+        }
         // uniqueness + the neighbours of the winner
         uint32_t flags = 0, sm = 0, spv = 0;
         const int thr = minS * 100, mul = 100 - g.uniq;
@@ -597,6 +630,19 @@ __global__ void k_fill_s16(int16_t* p, size_t pitch_e, size_t stride_e, int W, i
 #include "sgbm_cost.hpp"
 namespace camd {
 
+// MODE_SGBM_3WAY: rows of the final raw disparity come from the stripe that owns them
+__global__ __launch_bounds__(256) void k_gather_stripes(const int16_t* __restrict__ rawv, size_t rawv_stride_e,
+                                                        int16_t* __restrict__ raw, size_t raw_stride_e, int W, int H,
+                                                        int stripe_sz, CostRanges cr)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, pair = blockIdx.z;
+    if (x >= W) return;
+    const int s = min(y / stripe_sz, cr.n - 1);
+    raw[(size_t)pair * raw_stride_e + (size_t)y * W + x] =
+        rawv[(size_t)(pair * cr.n + s) * rawv_stride_e + (size_t)(y - cr.start[s]) * W + x];
+}
+
+
 // defined in post.hip
 int launch_median3(const int16_t* src, size_t src_pitch_e, size_t src_stride_e, int16_t* dst,
                    size_t dst_pitch_e, size_t dst_stride_e, int w, int h, int batch, hipStream_t st);
@@ -615,7 +661,12 @@ static const char* kStageNames[ST_COUNT] = {"cost", "hsum", "vsum", "scan", "sca
 }  // namespace camd
 
 struct camd_sgbm {
-    camd::Geom g;
+    camd::Geom g;         // the image
+    camd::Geom ga;        // what the aggregation kernels see: g, or (MODE_SGBM_3WAY) one stripe of at most ga.H rows
+    camd::CostRanges cr;  // row ranges of the cost volume: the image, or the 3WAY stripes (each a "virtual pair")
+    int stripe_sz;        // 3WAY: rows a stripe owns
+    int16_t* rawv;        // 3WAY: raw disparity per virtual pair [max_batch * cr.n][ga.H][W]
+    int way3_simd_lanes;  // 3WAY winner-take-all tie rule: 8 = cv2's SSE / NEON builds (default), 1 = scalar build
     camd_sgbm_params params;
     int max_batch;
     size_t vol_elems;     // per pair, int16 elements of one volume
@@ -653,10 +704,9 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
         return CAMD_ERR_BAD_ARG;
     }
     if (p->numDisparities <= 0) { set_error("numDisparities must be > 0"); return CAMD_ERR_BAD_ARG; }
-    if (p->mode != CAMD_MODE_SGBM && p->mode != CAMD_MODE_HH && p->mode != CAMD_MODE_HH4) {
-        set_error("mode %d not implemented (MODE_SGBM=0, MODE_HH=1, MODE_HH4=3; MODE_SGBM_3WAY=2, cv2's variant of four "
-                  "row stripes x three directions, is not: see INTEGRATION.md)", p->mode);
-        return CAMD_ERR_UNSUPPORTED;
+    if (p->mode < CAMD_MODE_SGBM || p->mode > CAMD_MODE_HH4) {
+        set_error("mode %d unknown (MODE_SGBM=0, MODE_HH=1, MODE_SGBM_3WAY=2, MODE_HH4=3)", p->mode);
+        return CAMD_ERR_BAD_ARG;
     }
     memset(g, 0, sizeof(*g));
     g->W = width; g->H = height; g->cn = cn;
@@ -673,9 +723,10 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
     g->P2 = P2 > g->P1 + 1 ? P2 : g->P1 + 1;
     int bs = p->blockSize > 0 ? p->blockSize : 5;
     g->SW2 = bs / 2;
+    if (p->mode == CAMD_MODE_SGBM_3WAY && p->blockSize <= 0) g->SW2 = 1;  // cv2's 3-way loop: SADWindowSize > 0 ? /2 : 1
     g->ftzero = (p->preFilterCap > 15 ? p->preFilterCap : 15) | 1;
     g->mode = p->mode;
-    g->npaths = p->mode == CAMD_MODE_HH ? 8 : (p->mode == CAMD_MODE_HH4 ? 4 : 5);
+    g->npaths = p->mode == CAMD_MODE_HH ? 8 : (p->mode == CAMD_MODE_HH4 ? 4 : (p->mode == CAMD_MODE_SGBM_3WAY ? 3 : 5));
     g->speckleWindowSize = p->speckleWindowSize;
     g->speckleRange = p->speckleRange;
     if (2 * g->SW2 + 1 > HSUM_RING) {
@@ -705,6 +756,37 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Row ranges of the cost volume and the geometry the aggregation kernels see.  MODE_SGBM_3WAY: cv2's four fixed row
+// stripes (oracle/sgbm_ref.c compute_disparity_3way), each with its warm-up overlap, each a "virtual pair".
+static int cost_ranges(const Geom& g, int block_size_raw, CostRanges* cr, int* stripe_sz, int* max_rows)
+{
+    if (g.mode != CAMD_MODE_SGBM_3WAY) {
+        cr->n = 1;
+        cr->start[0] = 0; cr->rows[0] = g.H;
+        for (int i = 1; i < 4; i++) { cr->start[i] = 0; cr->rows[i] = 0; }
+        *stripe_sz = g.H;
+        *max_rows = g.H;
+        return CAMD_OK;
+    }
+    const int ns = 4, sz = div_up(g.H, ns), ov = (block_size_raw / 2 + 1) + div_up(sz, 10);
+    cr->n = ns;
+    *stripe_sz = sz;
+    *max_rows = 0;
+    for (int s = 0; s < ns; s++) {
+        int a = s * sz - ov, b = (s + 1) * sz < g.H ? (s + 1) * sz : g.H;
+        if (s > 0 && s * sz < g.H && a < 0) {
+            set_error("image height %d too small for MODE_SGBM_3WAY with blockSize %d (a stripe of %d rows needs a warm-up "
+                      "of %d rows above it)", g.H, block_size_raw, sz, ov);
+            return CAMD_ERR_UNSUPPORTED;
+        }
+        a = a < 0 ? 0 : (a > g.H ? g.H : a);
+        cr->start[s] = a;
+        cr->rows[s] = b > a ? b - a : 0;
+        if (cr->rows[s] > *max_rows) *max_rows = cr->rows[s];
+    }
+    return CAMD_OK;
+}
+
 // work of one pair in units of one 1080p / D=128 volume: the AUTO path rule and its workspace follow it
 static double pair_work(const Geom& g) { return ((double)g.H * g.W1 * g.Dp) / (1080.0 * 1792.0 * 128.0); }
 static double auto_concurrent_limit(const Geom& g) { return g.mode == CAMD_MODE_HH ? 8.0 : 4.0; }
@@ -724,7 +806,7 @@ template <bool FIRST>
 static int launch_scan(const camd_sgbm* h, const int (*dirs)[2], int ndirs, uint16_t* S, size_t dir_stride,
                        int batch, hipStream_t st)
 {
-    const Geom& g = h->g;
+    const Geom& g = h->ga;
     ScanDirs sd;
     int maxlines = 0;
     for (int i = 0; i < 8; i++) {
@@ -759,13 +841,14 @@ static int launch_scan(const camd_sgbm* h, const int (*dirs)[2], int ndirs, uint
 static int launch_wta(const camd_sgbm* h, const uint16_t* S, int nvol, size_t dir_stride, int16_t* disp,
                       size_t pitch_e, size_t stride_e, int batch, hipStream_t st)
 {
-    const Geom& g = h->g;
+    const Geom& g = h->ga;
+    const int tie_lanes = g.mode == CAMD_MODE_SGBM_3WAY ? h->way3_simd_lanes : 0;
     dim3 grid(g.H, batch);
     size_t lds = (size_t)g.W * 6;
     lds = align_up(lds, 16);
 #define CAMD_WTA(LN, NVV)                                                                       \
     hipLaunchKernelGGL((k_wta<LN, NVV>), grid, dim3(256), lds, st, S, disp, pitch_e, stride_e, g, \
-                       h->vol_elems, nvol, dir_stride)
+                       h->vol_elems, nvol, dir_stride, tie_lanes)
     if (g.lanes == 2) CAMD_WTA(2, 1);
     else if (g.lanes == 4) CAMD_WTA(4, 1);
     else if (g.lanes == 8) CAMD_WTA(8, 1);
@@ -827,18 +910,23 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     Geom g;
     if (normalise(p, width, height, channels, &g) != CAMD_OK || max_batch <= 0) return 0;
     size_t w1 = g.W1 > 0 ? (size_t)g.W1 : 0;
-    size_t vol = align_up((size_t)height * w1 * g.Dp * 2, 256);
+    CostRanges cr;
+    int stripe_sz, vrows;
+    if (cost_ranges(g, p->blockSize, &cr, &stripe_sz, &vrows) != CAMD_OK) return 0;
+    const bool way3 = g.mode == CAMD_MODE_SGBM_3WAY;
+    size_t vol = align_up((size_t)vrows * w1 * g.Dp * 2, 256);
     size_t raw = align_up((size_t)height * width * 2, 256);
-    size_t total = (size_t)max_batch * (2 * vol + raw);
+    size_t total = (size_t)max_batch * (2 * cr.n * vol + raw);
+    if (way3) total += (size_t)max_batch * cr.n * align_up((size_t)vrows * width * 2, 256);
     if (g.speckleWindowSize > 0) total += speckle_ws_bytes(width, height, max_batch);
-    const bool band_ok = w1 > 0 && g.uniq <= 99 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    const bool band_ok = !way3 && w1 > 0 && g.uniq <= 99 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
     if (band_ok) {
         const int R = BAND_THREADS / g.lanes;
         size_t nb = (size_t)div_up(height, R);
         total += (size_t)max_batch * nb * (band_erec_stride(g.W1, g.lanes, g.nv) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
         total += (size_t)max_batch * height * width * 6 + 8;
     }
-    total += (size_t)g.npaths * auto_concurrent_pairs(g, band_ok, max_batch) * vol;  // per-direction volumes (latency path)
+    if (!way3) total += (size_t)g.npaths * auto_concurrent_pairs(g, band_ok, max_batch) * vol;  // per-direction volumes (latency path)
     return total;
 }
 
@@ -859,19 +947,33 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     h->g = g;
     h->params = *p;
     h->max_batch = max_batch;
+    h->way3_simd_lanes = 8;
+    int vrows = height;
+    rc = cost_ranges(g, p->blockSize, &h->cr, &h->stripe_sz, &vrows);
+    if (rc != CAMD_OK) { delete h; return rc; }
+    const bool way3 = g.mode == CAMD_MODE_SGBM_3WAY;
+    if (way3 && 2 * g.SW2 + 1 > 11) {
+        set_error("MODE_SGBM_3WAY is implemented for blockSize <= 11");
+        delete h;
+        return CAMD_ERR_UNSUPPORTED;
+    }
+    h->ga = g;
+    h->ga.H = vrows;
     size_t w1 = g.W1 > 0 ? (size_t)g.W1 : 0;
-    h->vol_elems = align_up((size_t)height * w1 * g.Dp * 2, 256) / 2;
+    h->vol_elems = align_up((size_t)vrows * w1 * g.Dp * 2, 256) / 2;
     size_t raw_e = align_up((size_t)height * width * 2, 256) / 2;
+    const size_t nvol = (size_t)max_batch * h->cr.n;  // volumes: one per (virtual) pair
     hipError_t e = hipSuccess;
     if (w1 > 0) {
-        if (e == hipSuccess) e = hipMalloc((void**)&h->C, (size_t)max_batch * h->vol_elems * 2);
-        if (e == hipSuccess) e = hipMalloc((void**)&h->S, (size_t)max_batch * h->vol_elems * 2);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->C, nvol * h->vol_elems * 2);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->S, nvol * h->vol_elems * 2);
+        if (e == hipSuccess && way3) e = hipMalloc((void**)&h->rawv, nvol * align_up((size_t)vrows * width * 2, 256));
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->raw, (size_t)max_batch * raw_e * 2);
     size_t sws = speckle_ws_bytes(width, height, max_batch);
     if (e == hipSuccess && g.speckleWindowSize > 0) e = hipMalloc(&h->speckle_ws, sws);
     // band-wavefront path: instantiated for 16 lanes x {1,2} vectors and 8 lanes x 1 vector
-    h->band_ok = w1 > 0 && g.uniq <= 99 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    h->band_ok = !way3 && w1 > 0 && g.uniq <= 99 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
     h->path = 0;
     h->saturate = 1;
     h->epoch = 0;
@@ -893,7 +995,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         if (e == hipSuccess) e = hipHostMalloc((void**)&h->err_host, 4, hipHostMallocDefault);
         if (e == hipSuccess) *h->err_host = 0;
     }
-    h->smulti_cap = w1 > 0 ? auto_concurrent_pairs(g, h->band_ok, max_batch) : 0;
+    h->smulti_cap = w1 > 0 && !way3 ? auto_concurrent_pairs(g, h->band_ok, max_batch) : 0;
     if (e == hipSuccess && h->smulti_cap > 0)
         e = hipMalloc((void**)&h->Smulti, (size_t)g.npaths * h->smulti_cap * h->vol_elems * 2);
     if (e != hipSuccess) {
@@ -911,7 +1013,7 @@ int camd_sgbm_destroy(camd_sgbm* h)
     if (h->ev_ok)
         for (int i = 0; i <= ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
     (void)hipFree(h->C); (void)hipFree(h->S);
-    (void)hipFree(h->raw); (void)hipFree(h->speckle_ws);
+    (void)hipFree(h->raw); (void)hipFree(h->rawv); (void)hipFree(h->speckle_ws);
     (void)hipFree(h->E); (void)hipFree(h->flags); (void)hipFree(h->ticket); (void)hipFree(h->keys);
     (void)hipFree(h->d1); (void)hipFree(h->Smulti);
     if (h->err_host) (void)hipHostFree(h->err_host);
@@ -956,6 +1058,7 @@ int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
     else if (option == CAMD_OPT_KEEP_S) h->keep_S = value != 0;
     else if (option == CAMD_OPT_COST && value >= CAMD_COST_AUTO && value <= CAMD_COST_SPLIT) h->cost_path = value;
     else if (option == CAMD_OPT_SATURATE) h->saturate = value != 0;
+    else if (option == CAMD_OPT_3WAY_SIMD_LANES && (value == 1 || value == 8)) h->way3_simd_lanes = value;
     else { set_error("unknown option %d / value %d", option, value); return CAMD_ERR_BAD_ARG; }
     return CAMD_OK;
 }
@@ -1042,7 +1145,9 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     // U7: int16 overflow is possible at all only beyond this bound; below it SAT == wrap
     const bool may_overflow = (long long)K * K * g.cn * (2 * g.ftzero + 63) + g.P2 > 32767;
     const bool sat = h->saturate && may_overflow;
-    const bool fused = K <= 11 && h->cost_path != CAMD_COST_SPLIT;
+    const bool way3 = g.mode == CAMD_MODE_SGBM_3WAY;
+    const int vbatch = batch * h->cr.n;  // volumes this call fills (3WAY: four stripes per pair)
+    const bool fused = K <= 11 && (h->cost_path != CAMD_COST_SPLIT || way3);
     MARK(ST_COST);
     if (fused) {
         // waves per workgroup: one per 8 disparities, at least 4 (the staging needs up to 3 waves of lanes), at most
@@ -1055,17 +1160,17 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         // row chunks: enough workgroups for ~32 rounds over the chip, but the saturating recurrence must start at row 0
         int nchunks = 1;
         if (!sat) {
-            nchunks = div_up(8192, (long long)nstrips * ndblk * batch);
-            const int maxc = g.H / 32 > 1 ? g.H / 32 : 1;
+            nchunks = div_up(8192, (long long)nstrips * ndblk * vbatch);
+            const int maxc = h->ga.H / 32 > 1 ? h->ga.H / 32 : 1;
             nchunks = nchunks < 1 ? 1 : (nchunks > maxc ? maxc : nchunks);
         }
-        const int rb = div_up(g.H, nchunks);
-        nchunks = div_up(g.H, rb);
-        dim3 grid(nstrips, nchunks * ndblk, batch), block(64 * nw);
+        const int rb = div_up(h->ga.H, nchunks);  // rows per chunk, in the longest range
+        nchunks = div_up(h->ga.H, rb);
+        dim3 grid(nstrips, nchunks * ndblk, vbatch), block(64 * nw);
         const size_t lds = cost_lds_bytes(g.cn, nw);
 #define CAMD_COST(CNN, KK, SS)                                                                                       \
     hipLaunchKernelGGL((k_cost<CNN, KK, SS>), grid, block, lds, st, left, right, pitch, image_stride, h->C, g, rb, \
-                       nchunks, h->vol_elems)
+                       nchunks, h->vol_elems, h->cr)
 #define CAMD_COST_K(CNN)                                                                  \
     switch (K) {                                                                          \
         case 1: CAMD_COST(CNN, 1, false); break;                                          \
@@ -1147,6 +1252,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         else path = CAMD_PATH_BAND;
     }
     if (path == CAMD_PATH_BAND && !h->band_ok) path = CAMD_PATH_SCAN;
+    if (way3) path = CAMD_PATH_SCAN;  // three line scans per stripe (the stripes are independent "virtual pairs")
     // the per-direction volumes were sized in create / set_option: a larger batch takes the next best path
     if (path == CAMD_PATH_CONCURRENT && batch > mcap) path = h->band_ok ? CAMD_PATH_BAND : CAMD_PATH_SCAN;
     const bool band = path == CAMD_PATH_BAND;
@@ -1168,15 +1274,15 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         if (rc != CAMD_OK) return rc;
     } else {
         static const int dirs8[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1}};
-        static const int dirs4[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
-        const int (*dirs)[2] = g.mode == CAMD_MODE_HH4 ? dirs4 : dirs8;
+        static const int dirs4[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};  // MODE_SGBM_3WAY = the first three
+        const int (*dirs)[2] = (g.mode == CAMD_MODE_HH4 || way3) ? dirs4 : dirs8;
         if (multi) {
             int rc = launch_scan<true>(h, dirs, g.npaths, h->Smulti, dir_stride, batch, st);
             if (rc != CAMD_OK) return rc;
         } else {
             for (int i = 0; i < g.npaths; i++) {
-                int rc = i == 0 ? launch_scan<true>(h, dirs + i, 1, h->S, 0, batch, st)
-                                : launch_scan<false>(h, dirs + i, 1, h->S, 0, batch, st);
+                int rc = i == 0 ? launch_scan<true>(h, dirs + i, 1, h->S, 0, vbatch, st)
+                                : launch_scan<false>(h, dirs + i, 1, h->S, 0, vbatch, st);
                 if (rc != CAMD_OK) return rc;
             }
         }
@@ -1189,6 +1295,14 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
                            (size_t)g.W, raw_stride, g, h->err);
         CAMD_LAUNCH_CHECK();
         CAMD_HIP(hipMemcpyAsync(h->err_host, h->err, 4, hipMemcpyDeviceToHost, st));
+    } else if (way3) {
+        // winner-take-all + LR check per stripe row, then every image row is taken from the stripe that owns it
+        const size_t rawv_stride = align_up((size_t)h->ga.H * g.W * 2, 256) / 2;
+        int rc = launch_wta(h, h->S, 1, 0, h->rawv, (size_t)g.W, rawv_stride, vbatch, st);
+        if (rc != CAMD_OK) return rc;
+        hipLaunchKernelGGL(k_gather_stripes, dim3(div_up(g.W, 256), g.H, batch), dim3(256), 0, st, h->rawv, rawv_stride,
+                           h->raw, raw_stride, g.W, g.H, h->stripe_sz, h->cr);
+        CAMD_LAUNCH_CHECK();
     } else {
         int rc = multi ? launch_wta(h, h->Smulti, g.npaths, dir_stride, h->raw, (size_t)g.W, raw_stride, batch, st)
                        : launch_wta(h, h->S, 1, 0, h->raw, (size_t)g.W, raw_stride, batch, st);
@@ -1217,6 +1331,10 @@ int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* st
     const Geom& g = h->g;
     hipStream_t st = (hipStream_t)stream;
     if (which == 0 || which == 1) {
+        if (g.mode == CAMD_MODE_SGBM_3WAY) {
+            set_error("MODE_SGBM_3WAY keeps its volumes per stripe: only which = 2 (raw disparity) is available");
+            return CAMD_ERR_UNSUPPORTED;
+        }
         if (g.W1 <= 0) return CAMD_OK;
         const uint16_t* src = (which == 0 ? h->C : h->S) + (size_t)index * h->vol_elems;
         CAMD_HIP(hipMemcpyAsync(dst, src, (size_t)g.H * g.W1 * g.Dp * 2, hipMemcpyDeviceToDevice, st));

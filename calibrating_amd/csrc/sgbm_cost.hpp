@@ -78,6 +78,15 @@ __device__ __forceinline__ uint32_t lane_window_sum(uint32_t p)
     return p + wave_shr<1>(w10);
 }
 
+// Row ranges the cost volume is built for.  Every mode but MODE_SGBM_3WAY has ONE range, the image; 3WAY has one per
+// stripe (cv2 computes its stripes independently: the vertical box window is clamped at the stripe's first row, and
+// the volume of a stripe is stored as a "virtual pair" of its own, so that the aggregation kernels see independent
+// images).  start = image row of local row 0 (also the lower clamp of the window), rows = rows in the range.
+struct CostRanges {
+    int n;
+    int start[4], rows[4];
+};
+
 static inline size_t cost_lds_bytes(int cn, int nwaves)
 {
     const int es = cn == 1 ? 4 : 12, dw = nwaves * COST_DL;
@@ -93,7 +102,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <int CN, int K, bool SAT>
 __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
-                                               Geom g, int rb, int nchunks, size_t vol_stride)
+                                               Geom g, int rb, int nchunks, size_t vol_stride, CostRanges cr)
 {
     constexpr int DL = COST_DL;
     constexpr int ES = CN == 1 ? 4 : 12;  // dwords per staged entry: (p, lo, hi) per channel, padded to 16 bytes
@@ -105,7 +114,10 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6, DW = NW * DL;
     const int tid = threadIdx.x;
-    const int chunk = blockIdx.y % nchunks, dblk = blockIdx.y / nchunks, pair = blockIdx.z;
+    const int chunk = blockIdx.y % nchunks, dblk = blockIdx.y / nchunks;
+    const int vpair = blockIdx.z, pair = vpair / cr.n, ridx = vpair % cr.n;  // volume index, image index, range
+    const int ybase = cr.start[ridx], nrows = cr.rows[ridx];
+    if (chunk * rb >= nrows) return;  // (ranges shorter than the longest one: whole workgroup, before any barrier)
     const int W1 = g.W1, H = g.H;
     const int xo0 = blockIdx.x * XS, xs0 = xo0 - SW2;                 // first output column, column of lane 0
     const int cmin = max(xs0, 0), cmax = min(xs0 + 63, W1 - 1);       // clamped column range of the strip
@@ -123,10 +135,11 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     const int ftz = g.ftzero;
     const uint32_t ftz2 = (uint32_t)ftz | ((uint32_t)ftz << 16);
 
-    // rows: step r of the walk handles image row clamp(y0 - SW2 + r); output row y0 + r - (K-1)
-    const int y0 = chunk * rb, y1 = min(y0 + rb, H);
+    // rows (local to the range): step r of the walk handles image row clamp(ybase + y0 - SW2 + r, ybase, H-1); output
+    // row y0 + r - (K-1)
+    const int y0 = chunk * rb, y1 = min(y0 + rb, nrows);
     const int nsteps = (y1 - y0) + K - 1;
-    auto row_of = [&](int r) { return min(max(y0 - SW2 + r, 0), H - 1); };
+    auto row_of = [&](int r) { return min(max(ybase + y0 - SW2 + r, ybase), H - 1); };
 
     // ---- staging: one lane = one image column, neighbours by wave-wide DPP shifts ---------------------------------
     // The staged columns (NR of the right image, NL of the left) are cut into pieces of <= 60 columns; a piece sits
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     const int xo = xo0 + lane - (K - 1);                                           // output column of this lane
     const bool writer = lane >= K - 1 && xo < W1 && d0 < g.Dp;
     const bool first_col = xo == 0;
-    uint16_t* const outp = Cout + (size_t)pair * vol_stride + (size_t)(writer ? xo : 0) * g.Dp + d0;
+    uint16_t* const outp = Cout + (size_t)vpair * vol_stride + (size_t)(writer ? xo : 0) * g.Dp + d0;
 
     const uint32_t p2 = dup16((uint32_t)g.P2);
     uint32_t acc[NP], ring[K][NP];
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
                         // everywhere else (Cprev - sub) + add
                         const uint32_t a0 = pk_subsat_i16(pk_addsat_i16(acc[k], T), old);
                         const uint32_t a1 = pk_addsat_i16(pk_subsat_i16(acc[k], old), T);
-                        acc[k] = (first_col && y0 + r - (K - 1) + SW2 < H) ? a0 : a1;
+                        acc[k] = (first_col && ybase + y0 + r - (K - 1) + SW2 < H) ? a0 : a1;
                     } else {
                         acc[k] = pk_sub_u16(pk_add_u16(acc[k], T), old);
                     }

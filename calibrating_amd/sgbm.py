@@ -45,8 +45,9 @@ class StereoSGBM:
         'cost': cost-volume kernels, 0 = auto, 1 = fused k_cost (BT + KxK box sum -> C in one pass),
         2 = k_hsum + k_vsum (two passes through an intermediate volume).  All choices are bit-identical;
         'saturate': int16 overflow of the cost-volume sums, 1 = saturate like cv2's SIMD build (default),
-        0 = wrap like OpenCV's scalar build (differs only for blockSize >= 7 on extreme images)."""
-        opt = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3}[option]
+        0 = wrap like OpenCV's scalar build (differs only for blockSize >= 7 on extreme images);
+        'way3_simd_lanes': MODE_SGBM_3WAY's tie rule, 8 = cv2's SSE / NEON builds (default), 1 = scalar build."""
+        opt = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3, "way3_simd_lanes": 4}[option]
         self._options[opt] = int(value)
         if self._handle is not None:
             _native.check(_native.lib().camd_sgbm_set_option(self._handle, opt, int(value)))

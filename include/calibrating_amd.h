@@ -51,10 +51,9 @@ typedef struct camd_sgbm_params {
     int speckleWindowSize;
     int speckleRange;
     int mode; /* CAMD_MODE_SGBM = 0 (5 paths; the reference's call), CAMD_MODE_HH = 1 (8 paths),
-                 CAMD_MODE_HH4 = 3 (4 paths); cv2's MODE_SGBM_3WAY (2: four row stripes x three
-                 directions) is not implemented */
+                 CAMD_MODE_SGBM_3WAY = 2 (four row stripes x three paths), CAMD_MODE_HH4 = 3 (4 paths) */
 } camd_sgbm_params;
-enum { CAMD_MODE_SGBM = 0, CAMD_MODE_HH = 1, CAMD_MODE_HH4 = 3 };
+enum { CAMD_MODE_SGBM = 0, CAMD_MODE_HH = 1, CAMD_MODE_SGBM_3WAY = 2, CAMD_MODE_HH4 = 3 };
 
 typedef struct camd_sgbm camd_sgbm;
 
@@ -84,7 +83,7 @@ int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* st
  *   CAMD_PATH_BAND            fused band-wavefront passes (throughput; D in (32, 256])
  *   CAMD_PATH_CONCURRENT      all directions at once into per-direction volumes (latency; <= 8 pairs per call)
  * CAMD_OPT_KEEP_S 1 = the band path also stores the final S volume (for camd_sgbm_debug_copy(which = 1)). */
-enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1, CAMD_OPT_COST = 2, CAMD_OPT_SATURATE = 3 };
+enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1, CAMD_OPT_COST = 2, CAMD_OPT_SATURATE = 3, CAMD_OPT_3WAY_SIMD_LANES = 4 };
 enum { CAMD_PATH_AUTO = 0, CAMD_PATH_SCAN = 1, CAMD_PATH_BAND = 2, CAMD_PATH_CONCURRENT = 3 };
 /* CAMD_OPT_COST selects how the matching-cost volume C is built (bit-identical results):
  *   CAMD_COST_AUTO (default)  the fused kernel where it is instantiated (blockSize <= 11), else the split pair

@@ -29,7 +29,7 @@ class SgbmParams(ctypes.Structure):
 
 class Switches(ctypes.Structure):
     _fields_ = [("lanczos_fix_group_lo", ctypes.c_int), ("bt_border_raw_tab0", ctypes.c_int),
-                ("cost_saturate", ctypes.c_int)]
+                ("cost_saturate", ctypes.c_int), ("way3_stripes", ctypes.c_int), ("way3_simd_lanes", ctypes.c_int)]
 
 
 def build(force=False):
@@ -259,6 +259,7 @@ def unrectify_depth(depth, M_row2, mapx, mapy):
     return out
 
 
-def set_switches(lanczos_fix_group_lo=4, bt_border_raw_tab0=1, cost_saturate=1):
-    s = Switches(int(lanczos_fix_group_lo), int(bt_border_raw_tab0), int(cost_saturate))
+def set_switches(lanczos_fix_group_lo=4, bt_border_raw_tab0=1, cost_saturate=1, way3_stripes=4, way3_simd_lanes=8):
+    s = Switches(int(lanczos_fix_group_lo), int(bt_border_raw_tab0), int(cost_saturate), int(way3_stripes),
+                 int(way3_simd_lanes))
     lib().oracle_set_switches(ctypes.byref(s))

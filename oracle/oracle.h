@@ -42,7 +42,7 @@ typedef struct oracle_sgbm_params {
     int uniquenessRatio;
     int speckleWindowSize;
     int speckleRange;
-    int mode; /* 0 = MODE_SGBM (5 paths, reference's call), 1 = MODE_HH (8 paths) */
+    int mode; /* 0 = MODE_SGBM (5 paths, reference's call), 1 = MODE_HH (8 paths), 2 = MODE_SGBM_3WAY, 3 = MODE_HH4 */
 } oracle_sgbm_params;
 
 /* switches for the points SURVEY.md Appendix A flags as uncertain (U-flags) */
@@ -54,6 +54,12 @@ typedef struct oracle_switches {
                                  universal-intrinsic v_int16 + / - / * (1, what shipped SIMD builds run;
                                  default) or wrap like the scalar (CostType) casts (0).  Identical whenever
                                  blockSize^2 * cn * (2*ftzero + 63) + P2 <= 32767. */
+    int way3_stripes;         /* U17: MODE_SGBM_3WAY row stripes; OpenCV fixes it at 4 "disregarding the number of
+                                 threads to make the results fully reproducible" */
+    int way3_simd_lanes;      /* U20: v_int16 lanes of the OpenCV build (8 = SSE / NEON, what x86-64 and aarch64 wheels
+                                 use; 16 = AVX2 baseline): MODE_SGBM_3WAY's winner-take-all keeps, per lane slot, the
+                                 LAST disparity that attains the slot minimum and then the smallest position among the
+                                 slots holding the global minimum; <= 1 = the scalar build (smallest disparity wins) */
 } oracle_switches;
 void oracle_set_switches(const oracle_switches* s);
 void oracle_get_switches(oracle_switches* s);

@@ -17,6 +17,7 @@
 
 #include <limits.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 typedef int16_t CostType;
@@ -26,7 +27,7 @@ typedef uint8_t PixType;
 enum { DISP_SHIFT = 4, DISP_SCALE = 1 << DISP_SHIFT };
 #define MAX_COST ((CostType)SHRT_MAX)
 
-static oracle_switches g_sw = {4, 1, 1};
+static oracle_switches g_sw = {4, 1, 1, 4, 8};
 void oracle_set_switches(const oracle_switches* s) { g_sw = *s; }
 void oracle_get_switches(oracle_switches* s) { *s = g_sw; }
 
@@ -621,11 +622,218 @@ static int compute_disparity_hh4(const PixType* img1, const PixType* img2, int w
     return 0;
 }
 
-/* mode dispatch: 0 / 1 -> computeDisparitySGBM, 3 -> computeDisparitySGBM_HH4 */
+/* ---- stereosgbm.cpp: computeDisparity3WaySGBM / SGBM3WayMainLoop (MODE_SGBM_3WAY = 2) -------------------------
+ * Restated from recollection of OpenCV 4.x (no source at hand; every point I am not sure of is a U-flag in DESIGN.md):
+ *   - the image is cut into `nstripes` = 4 horizontal stripes (fixed "to make the results fully reproducible"),
+ *     stripe_sz = ceil(height / nstripes); a stripe starts `stripe_overlap` = blockSize/2 + 1 + ceil(0.1 * stripe_sz)
+ *     rows early to warm up the vertical path and the box sums, and writes only its own rows;
+ *   - per row: C (same BT cost + box sum + P2 as the other modes, but the vertical window is clamped at the stripe's
+ *     first row), then a left-to-right pass that updates L_left (zero state at the row's left border) and, in place,
+ *     L_top (zero state at the stripe's first row), then a right-to-left pass that updates L_right, sums the three
+ *     and picks the winner; uniqueness (only if uniquenessRatio > 0), right-view map, sub-pixel, LR check as in SGBM;
+ *   - SW2 = SH2 = blockSize > 0 ? blockSize/2 : 1 (not the "5 -> 2" of the other modes);
+ *   - the winner-take-all of the CV_SIMD build is not "smallest d": see oracle_switches.way3_simd_lanes.           */
+static void way3_winner(const CostType* tot, int D, int lanes, int* best_io, int* min_io)
+{
+    int best = *best_io, minc = SHRT_MAX; /* best_d survives from the previous pixel when nothing is below SHRT_MAX */
+    int E = 0;
+    if (lanes > 1) {
+        E = (D % lanes == 0) ? D : lanes * ((D - 1) / lanes);
+        if (E > 0) {
+            int m = SHRT_MAX, pos = -1;
+            for (int d = 0; d < E; d++) m = imin(m, tot[d]);
+            for (int j = 0; j < lanes; j++) { /* per lane slot: the LAST d attaining the slot minimum */
+                int sm = SHRT_MAX, sp = -1;
+                for (int d = j; d < E; d += lanes)
+                    if (tot[d] <= sm) { sm = tot[d]; sp = d; }
+                if (sm == m && (pos < 0 || sp < pos)) pos = sp; /* smallest position among the slots holding it */
+            }
+            minc = m;
+            best = pos;
+        }
+    }
+    for (int d = E; d < D; d++) /* scalar build / scalar tail: strictly smaller wins */
+        if (tot[d] < minc) { minc = tot[d]; best = d; }
+    *best_io = best;
+    *min_io = minc;
+}
+
+static int compute_disparity_3way(const PixType* img1, const PixType* img2, int width, int height, int cn, size_t step,
+                                  DispType* disp1, const oracle_sgbm_params* params)
+{
+    const int DISP_SHIFT = 4, DISP_SCALE = 1 << DISP_SHIFT;
+    int minD = params->minDisparity, maxD = minD + params->numDisparities, D = maxD - minD;
+    int uniquenessRatio = params->uniquenessRatio >= 0 ? params->uniquenessRatio : 10;
+    int disp12MaxDiff = params->disp12MaxDiff > 0 ? params->disp12MaxDiff : 1;
+    int P1 = params->P1 > 0 ? params->P1 : 2, P2 = imax(params->P2 > 0 ? params->P2 : 5, P1 + 1);
+    int minX1 = imax(maxD, 0), maxX1 = width + imin(minD, 0), width1 = maxX1 - minX1;
+    int INVALID_DISP = minD - 1, INVALID_DISP_SCALED = INVALID_DISP * DISP_SCALE;
+    int SW2 = params->blockSize > 0 ? params->blockSize / 2 : 1, SH2 = SW2;
+    const int TAB_OFS = 256 * 4, TAB_SIZE = 256 + TAB_OFS * 2;
+    PixType clipTab[256 + 256 * 4 * 2];
+    int ftzero = imax(params->preFilterCap, 15) | 1;
+    for (int k = 0; k < TAB_SIZE; k++) clipTab[k] = (PixType)(imin(imax(k - TAB_OFS, -ftzero), ftzero) + ftzero);
+
+    if (minX1 >= maxX1) {
+        for (size_t i = 0; i < (size_t)width * height; i++) disp1[i] = (DispType)INVALID_DISP_SCALED;
+        return 0;
+    }
+    if (width1 <= SW2) return -2; /* the first box sum would read cost columns that were never computed */
+    int nstripes = g_sw.way3_stripes > 0 ? g_sw.way3_stripes : 4;
+    int stripe_sz = (height + nstripes - 1) / nstripes;
+    int stripe_overlap = (params->blockSize / 2 + 1) + (int)ceil(0.1 * stripe_sz);
+    /* OpenCV: "the stereo images cannot be very small" -- a later stripe whose warm-up would start above row 0 has
+     * no well-defined row mapping there */
+    for (int s = 1; s < nstripes; s++)
+        if (s * stripe_sz < height && s * stripe_sz - stripe_overlap < 0) return -3;
+
+    size_t costW = (size_t)width1 * D;
+    int hsumRows = SH2 * 2 + 2;
+    CostType* C = (CostType*)malloc(costW * sizeof(CostType));
+    CostType* hsumBuf = (CostType*)malloc(costW * hsumRows * sizeof(CostType));
+    CostType* pixDiff = (CostType*)malloc(costW * sizeof(CostType));
+    CostType* hor = (CostType*)malloc((size_t)(width1 + 2) * D * sizeof(CostType));   /* L_left per column, then the total */
+    CostType* vert = (CostType*)malloc((size_t)(width1 + 2) * D * sizeof(CostType));  /* L_top per column */
+    CostType* vertMin = (CostType*)malloc((size_t)(width1 + 2) * sizeof(CostType));
+    CostType* rightBuf = (CostType*)malloc((size_t)D * 2 * sizeof(CostType));
+    CostType* tmpD = rightBuf + D;
+    CostType* disp2cost = (CostType*)malloc((size_t)width * sizeof(CostType));
+    DispType* disp2 = (DispType*)malloc((size_t)width * sizeof(DispType));
+    DispType* disp_row = (DispType*)malloc((size_t)width * sizeof(DispType));
+    PixType* tempBuf = (PixType*)malloc((size_t)width * (4 * cn + 2) + 64);
+    if (!C || !hsumBuf || !pixDiff || !hor || !vert || !vertMin || !rightBuf || !disp2cost || !disp2 || !disp_row || !tempBuf) {
+        free(C); free(hsumBuf); free(pixDiff); free(hor); free(vert); free(vertMin); free(rightBuf);
+        free(disp2cost); free(disp2); free(disp_row); free(tempBuf);
+        return -1;
+    }
+#define HS3(r) (hsumBuf + (size_t)((r) % hsumRows) * costW)
+
+    for (int s = 0; s < nstripes; s++) {
+        int src_start = imax(imin(s * stripe_sz - stripe_overlap, height), 0);
+        int src_end = imin((s + 1) * stripe_sz, height);
+        int first_out = s * stripe_sz; /* rows [first_out, src_end) belong to this stripe */
+        for (size_t i = 0; i < costW; i++) C[i] = (CostType)P2; /* BufferSGBM3Way: curCostVolumeLine starts at P2 */
+        memset(vert, 0, (size_t)(width1 + 2) * D * sizeof(CostType));
+        memset(vertMin, 0, (size_t)(width1 + 2) * sizeof(CostType));
+        int best_d = 0;
+
+        for (int y = src_start; y < src_end; y++) {
+            /* getRawMatchingCost(mem, y, src_start): the row buffer C is updated in place */
+            int dy1 = (y == src_start) ? src_start : y + SH2, dy2 = (y == src_start) ? src_start + SH2 : dy1;
+            for (int k = dy1; k <= dy2; k++) {
+                CostType* hsumAdd = HS3(imin(k, height - 1));
+                if (k < height) {
+                    calc_pixel_cost_bt(img1, img2, step, width, height, cn, k, minD, maxD, pixDiff, tempBuf, clipTab + TAB_OFS);
+                    for (int d = 0; d < D; d++) {
+                        CostType h = c_mul(pixDiff[d], SW2 + 1);
+                        for (int x = D; x <= SW2 * D; x += D) h = c_add(h, pixDiff[x + d]);
+                        hsumAdd[d] = h;
+                    }
+                    for (int x = D; x < width1 * D; x += D) {
+                        const CostType* pixAdd = pixDiff + imin(x + SW2 * D, (width1 - 1) * D);
+                        const CostType* pixSub = pixDiff + imax(x - (SW2 + 1) * D, 0);
+                        for (int d = 0; d < D; d++)
+                            hsumAdd[x + d] = c_add(c_sub(hsumAdd[x - D + d], pixSub[d]), pixAdd[d]);
+                    }
+                }
+                if (y > src_start) {
+                    const CostType* hsumSub = HS3(imax(y - SH2 - 1, src_start));
+                    /* same operation order as computeDisparitySGBM (it matters only past int16 saturation) */
+                    for (size_t i = 0; i < costW; i++)
+                        C[i] = (i < (size_t)D && k < height) ? c_sub(c_add(C[i], hsumAdd[i]), hsumSub[i])
+                                                              : c_add(c_sub(C[i], hsumSub[i]), hsumAdd[i]);
+                } else {
+                    int scale = k == src_start ? SH2 + 1 : 1;
+                    for (size_t i = 0; i < costW; i++) C[i] = c_add(C[i], c_mul(hsumAdd[i], scale));
+                }
+            }
+
+            for (int x = 0; x < width; x++) {
+                disp_row[x] = disp2[x] = (DispType)INVALID_DISP_SCALED;
+                disp2cost[x] = SHRT_MAX;
+            }
+            /* forward pass: L_left (column x at hor[(x+1)*D], zero border at hor[0]) and L_top in place */
+            memset(hor, 0, (size_t)D * sizeof(CostType));
+            int leftMin = 0;
+            for (int x = 0; x < width1; x++) {
+                const CostType* Cp = C + (size_t)x * D;
+                const CostType* lprev = hor + (size_t)x * D;
+                CostType* left = hor + (size_t)(x + 1) * D;
+                CostType* top = vert + (size_t)(x + 1) * D;
+                int lP2 = leftMin + P2, tP2 = vertMin[x + 1] + P2, lmin = SHRT_MAX, tmin = SHRT_MAX;
+                memcpy(tmpD, top, (size_t)D * sizeof(CostType));
+                for (int d = 0; d < D; d++) {
+                    int lm = d > 0 ? lprev[d - 1] : SHRT_MAX, lp = d < D - 1 ? lprev[d + 1] : SHRT_MAX;
+                    int tm = d > 0 ? tmpD[d - 1] : SHRT_MAX, tp = d < D - 1 ? tmpD[d + 1] : SHRT_MAX;
+                    left[d] = sat16(Cp[d] + imin(imin(lm + P1, lp + P1), imin((int)lprev[d], lP2)) - lP2);
+                    top[d] = sat16(Cp[d] + imin(imin(tm + P1, tp + P1), imin((int)tmpD[d], tP2)) - tP2);
+                    lmin = imin(lmin, left[d]);
+                    tmin = imin(tmin, top[d]);
+                }
+                leftMin = lmin;
+                vertMin[x + 1] = (CostType)tmin;
+            }
+            /* backward pass: L_right in place, total = right + left + top, winner */
+            memset(rightBuf, 0, (size_t)D * sizeof(CostType));
+            int rightMin = 0;
+            for (int x = width1 - 1; x >= 0; x--) {
+                const CostType* Cp = C + (size_t)x * D;
+                CostType* tot = hor + (size_t)(x + 1) * D;
+                const CostType* top = vert + (size_t)(x + 1) * D;
+                int rP2 = rightMin + P2, rmin = SHRT_MAX, min_cost;
+                memcpy(tmpD, rightBuf, (size_t)D * sizeof(CostType));
+                for (int d = 0; d < D; d++) {
+                    int rm = d > 0 ? tmpD[d - 1] : SHRT_MAX, rp = d < D - 1 ? tmpD[d + 1] : SHRT_MAX;
+                    rightBuf[d] = sat16(Cp[d] + imin(imin(rm + P1, rp + P1), imin((int)tmpD[d], rP2)) - rP2);
+                    rmin = imin(rmin, rightBuf[d]);
+                    tot[d] = sat16(sat16(rightBuf[d] + tot[d]) + top[d]);
+                }
+                rightMin = rmin;
+                way3_winner(tot, D, g_sw.way3_simd_lanes, &best_d, &min_cost);
+                if (min_cost >= SHRT_MAX) continue; /* every total saturated: no winner */
+                int d;
+                if (uniquenessRatio > 0) {
+                    for (d = 0; d < D; d++)
+                        if (tot[d] * (100 - uniquenessRatio) < min_cost * 100 && abs(d - best_d) > 1) break;
+                    if (d < D) continue;
+                }
+                d = best_d;
+                int _x2 = x + minX1 - d - minD;
+                if (_x2 >= 0 && _x2 < width && disp2cost[_x2] > min_cost) {
+                    disp2cost[_x2] = (CostType)min_cost;
+                    disp2[_x2] = (DispType)(d + minD);
+                }
+                if (0 < d && d < D - 1) {
+                    int denom2 = imax(tot[d - 1] + tot[d + 1] - 2 * tot[d], 1);
+                    d = d * DISP_SCALE + ((tot[d - 1] - tot[d + 1]) * DISP_SCALE + denom2) / (denom2 * 2);
+                } else
+                    d *= DISP_SCALE;
+                disp_row[x + minX1] = (DispType)(d + minD * DISP_SCALE);
+            }
+            for (int x = minX1; x < maxX1; x++) {
+                int d1 = disp_row[x];
+                if (d1 == INVALID_DISP_SCALED) continue;
+                int _d = d1 >> DISP_SHIFT, d_ = (d1 + DISP_SCALE - 1) >> DISP_SHIFT;
+                int _x = x - _d, x_ = x - d_;
+                if (0 <= _x && _x < width && disp2[_x] >= minD && abs(disp2[_x] - _d) > disp12MaxDiff &&
+                    0 <= x_ && x_ < width && disp2[x_] >= minD && abs(disp2[x_] - d_) > disp12MaxDiff)
+                    disp_row[x] = (DispType)INVALID_DISP_SCALED;
+            }
+            if (y >= first_out) memcpy(disp1 + (size_t)y * width, disp_row, (size_t)width * sizeof(DispType));
+        }
+    }
+#undef HS3
+    free(C); free(hsumBuf); free(pixDiff); free(hor); free(vert); free(vertMin); free(rightBuf);
+    free(disp2cost); free(disp2); free(disp_row); free(tempBuf);
+    return 0;
+}
+
+/* mode dispatch: 0 / 1 -> computeDisparitySGBM, 2 -> computeDisparity3WaySGBM, 3 -> computeDisparitySGBM_HH4 */
 static int compute_disparity(const PixType* img1, const PixType* img2, int width, int height, int cn, size_t step,
                              DispType* disp1, const oracle_sgbm_params* params, const capture* cap)
 {
     if (params->mode == 3) return compute_disparity_hh4(img1, img2, width, height, cn, step, disp1, params, cap);
+    if (params->mode == 2) return compute_disparity_3way(img1, img2, width, height, cn, step, disp1, params);
     return compute_disparity_sgbm(img1, img2, width, height, cn, step, disp1, params, cap);
 }
 
@@ -740,7 +948,7 @@ static int check_args(const oracle_sgbm_params* p, int width, int height, int cn
 {
     if (!p || width <= 0 || height <= 0 || (cn != 1 && cn != 3)) return -1;
     if (p->numDisparities <= 0) return -1;
-    if (p->mode != 0 && p->mode != 1 && p->mode != 3) return -1; /* MODE_SGBM_3WAY (2): result depends on cv2's thread count */
+    if (p->mode < 0 || p->mode > 3) return -1;
     return 0;
 }
 

@@ -61,6 +61,10 @@ def sgbm_cases():
     c.append(_sgbm("small_gray", 100, 48, 256, 128, 1, **_std(1, 128, 5)))
     c.append(_sgbm("small_hh4", 101, 40, 200, 64, 3, **_std(3, 64, 5, mode=3)))
     c.append(_sgbm("neg_mind_hh", 104, 30, 128, 48, 1, **_std(1, 48, 7, minDisparity=-7, mode=1)))
+    # MODE_SGBM_3WAY (four row stripes x three directions): U16-U20
+    c.append(_sgbm("way3_rgb", 110, 96, 260, 64, 3, **_std(3, 64, 5, mode=2)))
+    c.append(_sgbm("way3_gray_d50_block3", 111, 80, 200, 50, 1, **_std(1, 50, 3, mode=2)))
+    c.append(_sgbm("way3_default_block", 112, 64, 160, 16, 1, numDisparities=16, mode=2))
     c.append(_sgbm("u1_disp12_zero", 105, 30, 160, 32, 1, **_std(1, 32, 5, disp12MaxDiff=0)))
     c.append(_sgbm("u1_disp12_negative", 105, 30, 160, 32, 1, **_std(1, 32, 5, disp12MaxDiff=-1)))
     c.append(_sgbm("u2_defaults_all_zero", 106, 30, 160, 16, 1, numDisparities=16))
@@ -83,6 +87,12 @@ def sgbm_cases():
         full.update(extra)
         c.append(dict(name=nm, stage="sgbm", inputs=dict(left=l, right=r,
                                                          params=np.array([full[k] for k in SGBM_NAMES], np.int32))))
+    # U20: every total ties (constant 15 = what the BT border columns carry): the winner shows the tie rule of the build
+    flat = np.full((72, 220), 15, np.uint8)
+    full = {k: 0 for k in SGBM_NAMES}
+    full.update(dict(numDisparities=64, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, mode=2))
+    c.append(dict(name="way3_u20_all_ties", stage="sgbm",
+                  inputs=dict(left=flat, right=flat, params=np.array([full[k] for k in SGBM_NAMES], np.int32))))
     # U11: texture only in the two border columns
     bl = np.full((24, 120, 1), 90, np.uint8); br = bl.copy()
     bl[:, 0] = 255; bl[:, -1] = 0; br[:, 0] = 0; br[:, -1] = 255

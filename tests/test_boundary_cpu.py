@@ -61,8 +61,12 @@ def test_argument_validation_without_gpu():
     h = ctypes.c_void_p()
     assert lib.camd_sgbm_create(ctypes.byref(bad), 64, 64, 1, 1, ctypes.byref(h)) == _native.CAMD_ERR_BAD_ARG
     assert "numDisparities" in _native.last_error()
-    m3 = _native.SgbmParams(numDisparities=16, mode=2)
-    assert lib.camd_sgbm_create(ctypes.byref(m3), 64, 64, 1, 1, ctypes.byref(h)) == _native.CAMD_ERR_UNSUPPORTED
+    m3 = _native.SgbmParams(numDisparities=16, mode=5)
+    assert lib.camd_sgbm_create(ctypes.byref(m3), 64, 64, 1, 1, ctypes.byref(h)) == _native.CAMD_ERR_BAD_ARG
+    # MODE_SGBM_3WAY needs room for its stripes' warm-up rows
+    small = _native.SgbmParams(numDisparities=16, blockSize=11, mode=2)
+    assert lib.camd_sgbm_workspace_bytes(ctypes.byref(small), 64, 12, 1, 1) == 0
+    assert lib.camd_sgbm_workspace_bytes(ctypes.byref(small), 64, 64, 1, 1) > 0
 
 
 def test_interpolation_tables_three_independent_builders():

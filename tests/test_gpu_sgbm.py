@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+import calibrating_amd as ca  # noqa: E402
 from calibrating_amd import StereoSGBM_create, synthetic  # noqa: E402
 
 
@@ -178,3 +179,60 @@ def test_sgbm_full_size_rows_vs_oracle(oracle):
         p = _params(3, D, 5, 0, mode)
         got = StereoSGBM_create(**p).compute(left, right)
         assert np.array_equal(got, oracle.sgbm_compute(left, right, **p))
+
+
+# ---- MODE_SGBM_3WAY (cv2's four row stripes x three directions) ------------------------------------------------
+@pytest.mark.parametrize("H,W,D,cn,bs,minD,extra", [
+    (64, 200, 64, 1, 5, 0, {}),
+    (90, 260, 128, 3, 5, 0, {}),
+    (75, 300, 50, 3, 3, 0, {}),                       # D not a multiple of 8: SIMD region + scalar tail of the tie rule
+    (81, 180, 24, 1, 7, -5, {}),
+    (100, 240, 96, 3, 11, 2, dict(speckleWindowSize=60, speckleRange=2, uniquenessRatio=5)),
+    (68, 160, 16, 1, 0, 0, dict(uniquenessRatio=0)),   # blockSize 0 -> radius 1 in this mode; uniqueness test off
+    (97, 330, 200, 1, 5, 0, {}),                      # D > 128: two 8-groups per lane
+])
+def test_sgbm_3way_vs_oracle(oracle, H, W, D, cn, bs, minD, extra):
+    left, right = synthetic.rectified_pair(seed=21, H=H, W=W, D=max(D, 8), cn=cn)
+    b = bs if bs > 0 else 3
+    p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=8 * cn * b * b, P2=32 * cn * b * b, disp12MaxDiff=1,
+             uniquenessRatio=10, mode=ca.MODE_SGBM_3WAY)
+    p.update(extra)
+    m = ca.StereoSGBM_create(**p)
+    got = m.compute(left, right)
+    want = oracle.sgbm_compute(left, right, **p)
+    assert np.array_equal(got, want), "%d of %d pixels differ" % ((got != want).sum(), got.size)
+    assert (got[:, max(minD + D, 0):] >= minD * 16).mean() > 0.2  # (sanity: the matchable columns mostly match)
+    # the raw stage too, and a batch of the same pair twice
+    assert np.array_equal(m.debug_volume("raw").cpu().numpy(), oracle.sgbm_compute(left, right, raw=True, **p))
+    both = m.compute(np.stack([left, left]), np.stack([right, right]))
+    assert np.array_equal(both[0], want) and np.array_equal(both[1], want)
+
+
+@pytest.mark.parametrize("lanes", [8, 1])
+def test_sgbm_3way_tie_rule(oracle, lanes):
+    """An image on which EVERY total ties (constant 15 = the value the BT border columns carry, so even the image
+    borders do not break the tie): the winner is decided by the tie rule alone -- cv2's SIMD lane-slot rule (default:
+    the last disparity of each of the 8 slots, then the smallest of those = D - 8 for D % 8 == 0) or the scalar build's
+    smallest d.  D = 50 exercises the SIMD region [0, 48) + scalar tail {48, 49}."""
+    H, W = 72, 220
+    flat = np.full((H, W), 15, np.uint8)
+    try:
+        oracle.set_switches(way3_simd_lanes=lanes)
+        for D, winner8 in ((64, 56), (50, 40)):
+            p = dict(minDisparity=0, numDisparities=D, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, uniquenessRatio=0,
+                     mode=ca.MODE_SGBM_3WAY)
+            m = ca.StereoSGBM_create(**p)
+            m.set_option("way3_simd_lanes", lanes)
+            got = m.compute(flat, flat)
+            want = oracle.sgbm_compute(flat, flat, **p)
+            assert np.array_equal(got, want), (lanes, D, (got != want).sum())
+            raw = oracle.sgbm_compute(flat, flat, raw=True, **p)
+            assert raw[H // 2, W - 1] == (winner8 * 16 if lanes == 8 else 0), (lanes, D, raw[H // 2, W - 1])
+    finally:
+        oracle.set_switches()
+
+
+def test_sgbm_3way_refuses_tiny_images():
+    with pytest.raises(ValueError, match="3WAY"):
+        ca.StereoSGBM_create(numDisparities=16, blockSize=11, mode=ca.MODE_SGBM_3WAY).compute(
+            np.zeros((12, 64), np.uint8), np.zeros((12, 64), np.uint8))
