@@ -94,7 +94,10 @@ enum { CAMD_COST_AUTO = 0, CAMD_COST_FUSED = 1, CAMD_COST_SPLIT = 2 };
  *   1 (default)  saturate like OpenCV's CV_SIMD build (v_int16 + / -), which is what cv2 wheels run
  *   0            wrap modulo 2^16 like OpenCV's scalar build
  * The two differ only if blockSize^2 * channels * (2*ftzero + 63) + P2 > 32767 AND the image content drives a
- * window sum past 32767 (e.g. blockSize >= 11 on RGB with a large preFilterCap). */
+ * window sum past 32767 (e.g. blockSize >= 11 on RGB with a large preFilterCap).
+ * CAMD_OPT_3WAY_SIMD_LANES (MODE_SGBM_3WAY only): 8 (default) = the winner-take-all tie rule of cv2's 8-lane SIMD builds
+ * (per lane slot the last disparity attaining the slot minimum, then the smallest of those), 1 = the scalar build's
+ * smallest disparity.  Only exact ties are affected. */
 int camd_sgbm_set_option(camd_sgbm* h, int option, int value);
 /* synchronises `stream` and reports whether a device-side bounded wait of the last computes timed out.
  * Without this call a timeout still cannot pass unnoticed: the affected call's disparities are written as

@@ -18,9 +18,9 @@ def _pair(seed, H, W, D, cn):
     return synthetic.rectified_pair(seed=seed, H=H, W=W, D=max(D, 8), cn=cn)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 3])
-@pytest.mark.parametrize("H,W,D,cn,bs,minD", [(48, 200, 64, 1, 5, 0), (40, 260, 128, 3, 5, 0), (36, 300, 96, 3, 11, 2),
-                                               (30, 150, 32, 1, 3, -5)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("H,W,D,cn,bs,minD", [(64, 200, 64, 1, 5, 0), (72, 260, 128, 3, 5, 0), (96, 300, 96, 3, 11, 2),
+                                               (60, 150, 32, 1, 3, -5)])
 def test_sgbm_oracle_equals_cv2(oracle, mode, H, W, D, cn, bs, minD):
     left, right = _pair(3, H, W, D, cn)
     p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=8 * cn * bs * bs, P2=32 * cn * bs * bs,
