@@ -150,6 +150,12 @@ def pipelined_steps(matchers, streams, lefts, rights, outs, steps, warmup, distr
     from calibrating_amd.parallel_pairs import timed_steps
     n = len(matchers)
     k = [0]
+    # set-up, not a step: the first compute on a handle touches its freshly allocated workspace (seconds for 80 GB),
+    # so every set runs once before the W warm-up steps -- whatever W is
+    for i in range(n):
+        with torch.cuda.stream(streams[i]):
+            matchers[i].compute(lefts[i], rights[i], out=outs[i])
+    torch.cuda.synchronize()
 
     def step():
         i = k[0] % n
