@@ -62,13 +62,18 @@ struct BandArgs {
 };
 
 // one SGM update: L = C + min(Lp, Lp[d-1]+P1, Lp[d+1]+P1, delta) - delta, packed u16, returns new delta
+// edge_lo / edge_hi: two registers that live across all steps and directions.  A DPP row shift leaves the lane without
+// a source (lane 0 of the row for row_shr, lane 15 for row_shl) untouched, so those lanes keep the MAX_COST sentinel
+// they were initialised with and the other lanes are overwritten every time: no per-use reload of the sentinel.
 template <int LANES, int NR, bool PAD>
 __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&Lp)[NR], uint32_t delta, const uint32_t (&c)[NR],
                                              uint32_t (&L)[NR], const uint32_t (&keep)[NR],
-                                             const uint32_t (&sent)[NR], uint32_t P1pk, uint32_t P2pk, int li)
+                                             const uint32_t (&sent)[NR], uint32_t P1pk, uint32_t P2pk, int li,
+                                             uint32_t& edge_lo, uint32_t& edge_hi)
 {
-    uint32_t prev_last = dpp_mov<DPP_ROW_SHR1>(SENT_PK, Lp[NR - 1]);
-    uint32_t next_first = dpp_mov<DPP_ROW_SHL1>(SENT_PK, Lp[0]);
+    edge_lo = dpp_mov<DPP_ROW_SHR1>(edge_lo, Lp[NR - 1]);
+    edge_hi = dpp_mov<DPP_ROW_SHL1>(edge_hi, Lp[0]);
+    uint32_t prev_last = edge_lo, next_first = edge_hi;
     if (LANES < 16) {
         if (li == 0) prev_last = SENT_PK;
         if (li == LANES - 1) next_first = SENT_PK;
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
         DS[0][k] = DS[1][k] = DS[2][k] = DS[3][k] = 0;
     }
     uint32_t dH = P2pk;
+    uint32_t edge_lo = SENT_PK, edge_hi = SENT_PK;  // see sgm_step
     dVs[0] = dVs[1] = P2pk;
     dDs[0] = dDs[1] = dDs[2] = dDs[3] = P2pk;
 
@@ -447,19 +453,19 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
                 for (int k = 0; k < NR; k++) s[k] = MODE != 0 ? sr[u][k] : 0u;
                 {
                     uint32_t L[NR];
-                    dH = sgm_step<LANES, NR, PAD>(LH, dH, cc, L, keep, sent, P1pk, P2pk, li);
+                    dH = sgm_step<LANES, NR, PAD>(LH, dH, cc, L, keep, sent, P1pk, P2pk, li, edge_lo, edge_hi);
 #pragma unroll
                     for (int k = 0; k < NR; k++) { LH[k] = L[k]; s[k] = pk_addsat_i16(s[k], L[k]); }
                 }
                 if (FULL) {
-                    dVo = sgm_step<LANES, NR, PAD>(Vin, dV, cc, LVo, keep, sent, P1pk, P2pk, li);
+                    dVo = sgm_step<LANES, NR, PAD>(Vin, dV, cc, LVo, keep, sent, P1pk, P2pk, li, edge_lo, edge_hi);
 #pragma unroll
                     for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LVo[k]);
                     if (DIAG) {
-                        dDo = sgm_step<LANES, NR, PAD>(Din, dD, cc, LDo, keep, sent, P1pk, P2pk, li);
+                        dDo = sgm_step<LANES, NR, PAD>(Din, dD, cc, LDo, keep, sent, P1pk, P2pk, li, edge_lo, edge_hi);
 #pragma unroll
                         for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LDo[k]);
-                        dAo = sgm_step<LANES, NR, PAD>(An, dAn, cc, LAo, keep, sent, P1pk, P2pk, li);
+                        dAo = sgm_step<LANES, NR, PAD>(An, dAn, cc, LAo, keep, sent, P1pk, P2pk, li, edge_lo, edge_hi);
 #pragma unroll
                         for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LAo[k]);
                     }
