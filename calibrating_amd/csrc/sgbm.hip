@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
 #pragma unroll
     for (int k = 0; k < NR; k++) Lp[k] = 0;
     uint32_t delta = P2pk;  // minLp = 0
+    uint32_t edge_lo = SENT_PK, edge_hi = SENT_PK;
 
     auto load = [&](const uint4* p, uint32_t* dst) {
 #pragma unroll
@@ -421,8 +422,10 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
             if (i < len) {
                 const uint32_t(&c)[NR] = cr[u];
                 // neighbours across lanes: d-1 of my first element, d+1 of my last element
-                uint32_t prev_last = dpp_mov<DPP_ROW_SHR1>(SENT_PK, Lp[NR - 1]);
-                uint32_t next_first = dpp_mov<DPP_ROW_SHL1>(SENT_PK, Lp[0]);
+                // (edge_lo / edge_hi persist: the lane a row shift leaves untouched keeps its MAX_COST sentinel)
+                edge_lo = dpp_mov<DPP_ROW_SHR1>(edge_lo, Lp[NR - 1]);
+                edge_hi = dpp_mov<DPP_ROW_SHL1>(edge_hi, Lp[0]);
+                uint32_t prev_last = edge_lo, next_first = edge_hi;
                 if (LANES < 16) {
                     if (li == 0) prev_last = SENT_PK;
                     if (li == LANES - 1) next_first = SENT_PK;
