@@ -92,6 +92,18 @@ class Cam(dict):
         rec.update(intrinsic_format_conversion(self.K))
         return rec if return_dict else write_record(rec, path)
 
+    # intrinsics by name and the fields of view in DEGREES (reference camera.py:500-530; its boxx trig works in degrees)
+    fx = property(lambda self: self.K[0, 0])
+    fy = property(lambda self: self.K[1, 1])
+    cx = property(lambda self: self.K[0, 2])
+    cy = property(lambda self: self.K[1, 2])
+
+    @property
+    def fovs(self):
+        half_x, half_y = self.xy[0] / 2 / self.fx, self.xy[1] / 2 / self.fy  # tangents of the half angles
+        deg = lambda t: float(np.degrees(2 * np.arctan(t)))  # noqa: E731
+        return dict(fov=deg(np.hypot(half_x, half_y)), fovx=deg(half_x), fovy=deg(half_y))
+
     def project_cam2_depth(cam1, cam2, depth2, T=None, interpolation=1.5):
         """Depth image of ``cam2`` re-projected into this camera (camera.py:298-309), on the GPU.
         ``T`` = pose of cam2 in this camera (4x4); the reference's fallback that derives it from calibration

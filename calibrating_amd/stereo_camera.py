@@ -157,6 +157,7 @@ class Stereo:
                  "\t t(cm): [%s]" % " ".join(str(v) for v in (self.t.reshape(3) * 100).round(2)),
                  "\t r(rodrigues): [%s] %.2f\u00b0" % (" ".join(str(v) for v in rvec.round(3)),
                                                     np.degrees(np.linalg.norm(rvec)))]
+        lines.append("\t cam1.fovs: %s" % ", ".join("%s=%s\u00b0" % (k, round(v, 2)) for k, v in self.cam1.fovs.items()))
         if hasattr(self, "retval"):
             lines.append("\t retval: %s" % self.retval)
         return "\n".join(lines) + "\n"
