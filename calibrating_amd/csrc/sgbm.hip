@@ -5,12 +5,11 @@
 // (/root/reference/calibrating/stereo_matching.py:48-58,63).  Not a port of OpenCV's row-incremental
 // CPU loop: the algorithm is re-stated in a data-parallel form (SURVEY.md Appendix A / DESIGN.md):
 //
-//   k_hsum         calcPixelCostBT + horizontal box sum.  A workgroup owns (row, 128 cost columns, all d):
-//                  it builds the clipped x-Sobel / raw planes and their half-pixel min/max of the image
-//                  columns it touches in LDS, packed (gradient | raw << 16) so the BT cost runs on packed
-//                  16-bit VALU ops; one wave = 64 consecutive disparities, lane j reads the right-image
-//                  entry of column x - d with ds_read_b128, the left entry is an LDS broadcast
-//   k_vsum         vertical box sum + P2  ->  C[y][x][d]  (int16, d fastest)
+//   k_cost         (sgbm_cost.hpp) calcPixelCostBT + blockSize x blockSize box sum + P2 -> C[y][x][d] in ONE pass:
+//                  lanes = columns, the workgroup walks rows; horizontal sum by wave-wide DPP shifts, vertical sum as a
+//                  register ring.  The default for blockSize <= 11.
+//   k_hsum, k_vsum the two-pass form of the same (round 1): BT + horizontal box sum into an intermediate volume, then
+//                  the vertical box sum + P2.  Kept for blockSize 13 / 15 and as an A/B reference (CAMD_COST_SPLIT).
 //   k_band         (sgbm_band.hpp) fused aggregation: four directions per pass + WTA in the last
 //   k_scan         one aggregation direction as independent line scans from a zero border state;
 //                  a line is owned by a 2..16-lane group (8*NV disparities per lane, packed u16x2),
