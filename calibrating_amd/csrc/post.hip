@@ -6,7 +6,7 @@
 // Speckle filter = connected components of the graph whose edges join 4-neighbours a, b with
 // a != newVal, b != newVal and |a - b| <= maxDiff; components of size <= maxSpeckleSize are
 // overwritten with newVal.  The relation is symmetric, so the components do not depend on OpenCV's
-// scan order and a lock-free union-find gives the identical result.
+// scan order and a lock-free union-find over horizontal runs gives the identical result.
 #include "common.hpp"
 
 namespace camd {
@@ -76,52 +76,104 @@ __device__ void uf_union(int* parent, int a, int b)
     }
 }
 
-// all kernels: blockIdx.z = image of the batch; parent / count hold 2*n ints per image (labels are local)
-__global__ __launch_bounds__(256) void k_cc_init(int* parent, int n)
+// All kernels: blockIdx.z = image of the batch; parent / count hold 2*n ints per image (labels are local); a block is
+// 256 consecutive pixels of one row, so a wave is 64 consecutive pixels.
+//
+// Horizontal structure comes for free: within a wave the pixels of a horizontal run (each connected to its left
+// neighbour) are found from one ballot, so
+//   k_cc_rows   points every pixel at the first pixel of its run-in-the-wave (no atomics at all),
+//   k_cc_merge  unions only (i) a run that continues across a wave boundary with the wave before and (ii) vertical
+//               neighbours -- and skips a vertical edge whenever the edge one pixel to the left together with the two
+//               horizontal edges already implies it (in smooth regions that leaves one union per wave and row),
+//   k_cc_count  adds the LENGTH of each run to its root with one atomic per run instead of one per pixel (a large
+//               component no longer serialises on a single counter),
+//   k_cc_apply  erases the components that are small enough.
+struct CcPix {
+    int v;          // pixel value
+    bool valid;     // != newVal
+    bool cl;        // connected to the left neighbour (same row)
+};
+
+__device__ __forceinline__ CcPix cc_load(const int16_t* __restrict__ row, int x, int w, int new_val, int max_diff)
 {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    int* par = parent + (size_t)blockIdx.z * 2 * n;
-    if (i < n) {
-        par[i] = i;
-        par[n + i] = 0;
+    CcPix p;
+    p.v = x < w ? row[x] : new_val;
+    p.valid = p.v != new_val;
+    const int l = dpp_perm<DPP_WAVE_SHR1>((uint32_t)p.v);  // lane 0 is handled by the caller
+    p.cl = p.valid && l != new_val && abs(p.v - l) <= max_diff;
+    return p;
+}
+
+// lane of the first pixel of this lane's run inside the wave, and whether the run reaches back past lane 0
+__device__ __forceinline__ int cc_run_start(unsigned long long clmask, int lane)
+{
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+    const unsigned long long breaks = ~clmask & upto;  // lanes <= lane that do NOT connect to their left
+    return breaks ? 63 - __clzll(breaks) : 0;
+}
+
+__global__ __launch_bounds__(256) void k_cc_rows(const int16_t* __restrict__ img, size_t pitch, size_t stride,
+                                                 int* parent, int w, int h, int new_val, int max_diff)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
+    img += (size_t)blockIdx.z * stride;
+    parent += (size_t)blockIdx.z * 2 * w * h;
+    CcPix p = cc_load(img + (size_t)y * pitch, x, w, new_val, max_diff);
+    if (lane == 0) p.cl = false;  // the link to the previous wave is an explicit union in k_cc_merge
+    const unsigned long long m = __ballot(p.cl);
+    if (x < w) {
+        const int i = y * w + x;
+        parent[i] = i - (lane - cc_run_start(m, lane));
+        parent[w * h + i] = 0;  // count
     }
 }
 
 __global__ __launch_bounds__(256) void k_cc_merge(const int16_t* __restrict__ img, size_t pitch, size_t stride,
                                                   int* parent, int w, int h, int new_val, int max_diff)
 {
-    int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
-    if (x >= w) return;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
     img += (size_t)blockIdx.z * stride;
     parent += (size_t)blockIdx.z * 2 * w * h;
-    int v = img[(size_t)y * pitch + x];
-    if (v == new_val) return;
-    int i = y * w + x;
-    if (x + 1 < w) {
-        int r = img[(size_t)y * pitch + x + 1];
-        if (r != new_val && abs(v - r) <= max_diff) uf_union(parent, i, i + 1);
-    }
-    if (y + 1 < h) {
-        int d = img[(size_t)(y + 1) * pitch + x];
-        if (d != new_val && abs(v - d) <= max_diff) uf_union(parent, i, i + w);
+    const int16_t* row = img + (size_t)y * pitch;
+    CcPix p = cc_load(row, x, w, new_val, max_diff);
+    // the row below, same columns
+    int d = new_val;
+    if (y + 1 < h && x < w) d = row[pitch + x];
+    const bool cd = p.valid && d != new_val && abs(p.v - d) <= max_diff;         // vertical edge (x, y)-(x, y+1)
+    const int dl = dpp_perm<DPP_WAVE_SHR1>((uint32_t)d);
+    const bool cl_down = d != new_val && dl != new_val && abs(d - dl) <= max_diff;  // (x-1, y+1)-(x, y+1)
+    const bool cd_left = dpp_perm<DPP_WAVE_SHR1>((uint32_t)cd) != 0;              // vertical edge one pixel to the left
+    if (x >= w || !p.valid) return;
+    const int i = y * w + x;
+    if (lane == 0) {
+        // across the wave boundary: lane 0 has no DPP neighbour, so it looks at memory
+        if (x > 0) {
+            const int l = row[x - 1];
+            if (l != new_val && abs(p.v - l) <= max_diff) uf_union(parent, i, i - 1);
+        }
+        if (cd) uf_union(parent, i, i + w);
+    } else if (cd && !(p.cl && cd_left && cl_down)) {
+        uf_union(parent, i, i + w);
     }
 }
 
 __global__ __launch_bounds__(256) void k_cc_count(const int16_t* __restrict__ img, size_t pitch, size_t stride,
-                                                  int* parent, int w, int h, int new_val)
+                                                  int* parent, int w, int h, int new_val, int max_diff)
 {
-    int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
-    if (x >= w) return;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
     img += (size_t)blockIdx.z * stride;
     parent += (size_t)blockIdx.z * 2 * w * h;
     int* count = parent + w * h;
-    if (img[(size_t)y * pitch + x] == new_val) return;
-    int i = y * w + x;
-    int r = uf_find(parent, i);
+    CcPix p = cc_load(img + (size_t)y * pitch, x, w, new_val, max_diff);
+    if (lane == 0) p.cl = false;
+    const unsigned long long m = __ballot(p.cl);
+    if (x >= w || !p.valid || p.cl) return;  // only the first pixel of a run-in-the-wave counts, for the whole run
+    const unsigned long long after = lane == 63 ? 0ull : (m >> (lane + 1));
+    const int len = 1 + (~after ? __ffsll((long long)~after) - 1 : 64);  // consecutive connected lanes behind it
+    const int i = y * w + x;
+    const int r = uf_find(parent, i);
     parent[i] = r;
-    atomicAdd(&count[r], 1);
+    atomicAdd(&count[r], len);
 }
 
 __global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, size_t stride,
@@ -136,8 +188,7 @@ __global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, si
     const int* count = parent + w * h;
     int16_t* p = img + (size_t)y * pitch + x;
     if (*p == new_val) return;
-    // the forest is final here, but path halving in k_cc_count may have left parent[i] pointing at an
-    // inner node: walk to the root (read only)
+    // pixel -> first pixel of its run -> (compressed by k_cc_count) root; walk read-only
     int r = y * w + x;
     for (int q = parent[r]; q != r; q = parent[r]) r = q;
     if (count[r] <= max_size) *p = (int16_t)new_val;
@@ -156,9 +207,10 @@ int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, 
     int n = w * h;
     int* parent = reinterpret_cast<int*>(ws);
     dim3 grid(div_up(w, 256), h, batch);
-    hipLaunchKernelGGL(k_cc_init, dim3(div_up(n, 256), 1, batch), dim3(256), 0, st, parent, n);
+    (void)n;
+    hipLaunchKernelGGL(k_cc_rows, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
     hipLaunchKernelGGL(k_cc_merge, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
-    hipLaunchKernelGGL(k_cc_count, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val);
+    hipLaunchKernelGGL(k_cc_count, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
     hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_size);
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
