@@ -43,6 +43,34 @@ def test_remap_bit_exact(oracle, cn, interp):
     assert np.array_equal(got, ref), "max |d| = %d" % np.abs(got.astype(int) - ref).max()
 
 
+@pytest.mark.parametrize("cn", [1, 3])
+def test_remap_borders_unaligned_base_and_padded_pitch(oracle, cn):
+    """Windows hanging over every edge and corner, with the image at an odd address inside a 0xFF-filled buffer and
+    rows padded with 0xFF: whatever the dword fetches pick up outside a row must be masked to the border constant."""
+    from calibrating_amd import _native
+    rng = np.random.default_rng(40 + cn)
+    sh, sw, dh, dw = 37, 53, 48, 200
+    img = rng.integers(0, 256, (sh, sw, cn), dtype=np.uint8)
+    pitch, lead = sw * cn + 5, 13
+    buf = np.full(lead + sh * pitch + 64, 255, np.uint8)
+    rows = np.lib.stride_tricks.as_strided(buf[lead:], (sh, sw * cn), (pitch, 1))
+    rows[:] = img.reshape(sh, sw * cn)
+    # a map that sweeps from 6 px outside to 6 px outside in both axes at fractional steps (all four corners)
+    mapx = np.tile(np.linspace(-6.3, sw + 5.7, dw, dtype=np.float32), (dh, 1))
+    mapy = np.tile(np.linspace(-6.6, sh + 5.4, dh, dtype=np.float32)[:, None], (1, dw))
+    mapx += rng.uniform(-0.4, 0.4, mapx.shape).astype(np.float32)
+    d_buf = torch.from_numpy(buf).cuda()
+    mx, my = torch.from_numpy(mapx).cuda(), torch.from_numpy(mapy).cuda()
+    for interp in (imgproc.INTER_LANCZOS4, imgproc.INTER_LINEAR):
+        out = torch.empty((dh, dw, cn), dtype=torch.uint8, device="cuda")
+        rc = _native.lib().camd_remap_u8(d_buf.data_ptr() + lead, sw, sh, cn, pitch, sh * pitch, mx.data_ptr(),
+                                         my.data_ptr(), out.data_ptr(), dw, dh, dw * cn, dh * dw * cn, interp, 0, 1,
+                                         _native.current_stream())
+        _native.check(rc, "remap")
+        ref = oracle.remap_u8(img if cn > 1 else img[..., 0], mapx, mapy, interp).reshape(dh, dw, cn)
+        assert np.array_equal(out.cpu().numpy(), ref)
+
+
 def test_remap_identity_and_shift(oracle):
     rng = np.random.default_rng(1)
     src = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
