@@ -43,7 +43,7 @@ PMC_PROFILE = "profiles/r02_pmc_traffic%s.json"  # committed rocprofv3 --pmc sum
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50, help="timed steps (default: >= 3 s of GPU work)")
+    ap.add_argument("--steps", type=int, default=80, help="timed steps (default: >= 3 s of GPU work)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
     ap.add_argument("--in-flight", type=int, default=2,
