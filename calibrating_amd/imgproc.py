@@ -7,7 +7,7 @@ import ctypes
 
 import numpy as np
 
-from . import _native
+from . import _native, hostio
 from ._native import INTER_LANCZOS4, INTER_LINEAR, INTER_NEAREST
 
 
@@ -57,7 +57,7 @@ def remap(src, mapx, mapy, interpolation=INTER_LANCZOS4, x_shift=0):
                                          int(interpolation), int(x_shift), n, _native.current_stream())
     _native.check(rc, "remap")
     dst = dst if batched else dst[0]
-    return dst.cpu().numpy() if was_np else dst
+    return hostio.to_host(dst) if was_np else dst
 
 
 def _dist_args(D):
@@ -137,7 +137,7 @@ def remap_fixed_bilinear(src, mapxy, mapa):
             dh, dw * cn, dh * dw * cn, n, _native.current_stream())
     _native.check(rc, "remap_fixed_bilinear")
     dst = dst if batched else dst[0]
-    return dst.cpu().numpy() if was_np else dst
+    return hostio.to_host(dst) if was_np else dst
 
 
 def medianBlur3_s16(disp):
@@ -150,7 +150,7 @@ def medianBlur3_s16(disp):
     with torch.cuda.device(s.device):
         rc = _native.lib().camd_median3_s16(s.data_ptr(), dst.data_ptr(), w, h, n, _native.current_stream())
     _native.check(rc, "medianBlur3_s16")
-    return dst.cpu().numpy() if was_np else dst
+    return hostio.to_host(dst) if was_np else dst
 
 
 def filterSpeckles(disp, newVal, maxSpeckleSize, maxDiff):
@@ -165,7 +165,7 @@ def filterSpeckles(disp, newVal, maxSpeckleSize, maxDiff):
         rc = _native.lib().camd_filter_speckles_s16(s.data_ptr(), w, h, int(newVal), int(maxSpeckleSize),
                                                     int(maxDiff), ws.data_ptr(), n, _native.current_stream())
     _native.check(rc, "filterSpeckles")
-    return s.cpu().numpy() if was_np else s
+    return hostio.to_host(s) if was_np else s
 
 
 def disp_to_depth(disp16, valid_mask, sgbm_min_disparity, add_min_disparity, translate, baseline_fx,
@@ -190,7 +190,7 @@ def disp_to_depth(disp16, valid_mask, sgbm_min_disparity, add_min_disparity, tra
                                               _native.current_stream())
     _native.check(rc, "disp_to_depth")
     if was_np:
-        return disparity.cpu().numpy(), depth.cpu().numpy()
+        return tuple(hostio.to_host(disparity, depth))
     return disparity, depth
 
 
@@ -209,4 +209,4 @@ def unrectify_depth(depth, M_row2, mapx, mapy):
         rc = _native.lib().camd_unrectify_depth(z.data_ptr(), w, h, M, mx.data_ptr(), my.data_ptr(),
                                                 out.data_ptr(), ow, oh, n, _native.current_stream())
     _native.check(rc, "unrectify_depth")
-    return out.cpu().numpy() if was_np else out
+    return hostio.to_host(out) if was_np else out

@@ -8,7 +8,7 @@ import ctypes
 
 import numpy as np
 
-from . import _native
+from . import _native, hostio
 from .geometry import inv3
 
 
@@ -67,7 +67,7 @@ def depth_to_point_cloud(depth, K, interpolation_rate=1, return_xyzuv=False):
     _native.check(rc, "depth_to_point_cloud")
     n = int(count.item())  # synchronises: the output length is data dependent
     out = torch.cat([pts[:n], uv[:n]], dim=1) if return_xyzuv else pts[:n]
-    return out.cpu().numpy() if was_np else out
+    return hostio.to_host(out) if was_np else out
 
 
 def apply_T_to_point_cloud(T, point_cloud):
@@ -83,7 +83,7 @@ def apply_T_to_point_cloud(T, point_cloud):
     _native.check(rc, "apply_T_to_point_cloud")
     if p.shape[1] > 3:
         out = torch.cat([out, p[:, 3:]], dim=1)
-    return out.cpu().numpy() if was_np else out
+    return hostio.to_host(out) if was_np else out
 
 
 def point_cloud_to_depth(points, K, xy, bg_value=0):
@@ -101,7 +101,7 @@ def point_cloud_to_depth(points, K, xy, bg_value=0):
                                                      float(bg_value), depth.data_ptr(), keys.data_ptr(),
                                                      _native.current_stream())
     _native.check(rc, "point_cloud_to_depth")
-    return depth.cpu().numpy() if was_np else depth
+    return hostio.to_host(depth) if was_np else depth
 
 
 def project_depth(depth2, K2, T_2in1, K1, xy1, interpolation_rate=1):
@@ -120,4 +120,4 @@ def project_depth(depth2, K2, T_2in1, K1, xy1, interpolation_rate=1):
                                               float(interpolation_rate), w1, h1, depth1.data_ptr(), keys.data_ptr(),
                                               _native.current_stream())
     _native.check(rc, "project_depth")
-    return depth1.cpu().numpy() if was_np else depth1
+    return hostio.to_host(depth1) if was_np else depth1

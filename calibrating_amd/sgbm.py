@@ -10,7 +10,7 @@ import ctypes
 
 import numpy as np
 
-from . import _native
+from . import _native, hostio
 
 MODE_SGBM = _native.MODE_SGBM
 MODE_HH = _native.MODE_HH
@@ -174,10 +174,11 @@ class StereoSGBM:
                 self._handle, left_t.data_ptr(), right_t.data_ptr(), w * cn, h * w * cn, out.data_ptr(),
                 w * 2, h * w * 2, n, _native.current_stream())
             _native.check(rc, "StereoSGBM.compute")
-            if is_np:
-                self.status()  # host path synchronises anyway: surface device-side timeouts here
         res = out.view(n, h, w) if batched else out.view(h, w)
-        return res.cpu().numpy() if is_np else res
+        if is_np:
+            res = hostio.to_host(res)
+            self.status()  # the copy synchronised: surface device-side timeouts here at no extra cost
+        return res
 
     # -- parity / measurement hooks ----------------------------------------------------------------
     def geometry(self):

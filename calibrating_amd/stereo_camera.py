@@ -20,7 +20,7 @@ in -> torch tensors out, zero-copy.
 """
 import numpy as np
 
-from . import geometry, imgproc
+from . import geometry, hostio, imgproc
 from .camera import Cam, read_record, write_record
 from .stereo_matching import SemiGlobalBlockMatching
 
@@ -223,7 +223,7 @@ class Stereo:
         rectify_img1 = imgproc.remap(i1, tb["map1x"], tb["map1y"], imgproc.INTER_LANCZOS4)
         rectify_img2 = imgproc.remap(i2, tb["map2x"], tb["map2y"], imgproc.INTER_LANCZOS4, x_shift=shift)
         if np1:
-            return [rectify_img1.cpu().numpy(), rectify_img2.cpu().numpy()]
+            return hostio.to_host(rectify_img1, rectify_img2)
         return [rectify_img1, rectify_img2]
 
     def _unrectify_tables(self, device):
@@ -239,7 +239,7 @@ class Stereo:
         mx, my = self._unrectify_tables(d.device)
         M = self.R1.T @ np.linalg.inv(self.K)
         out = imgproc.unrectify_depth(d, M[2], mx, my)
-        return out.cpu().numpy() if was_np else out
+        return hostio.to_host(out) if was_np else out
 
     def undistort_img(self, img1):
         i1, was_np = self._to_dev(self._get_img(img1))
@@ -248,7 +248,7 @@ class Stereo:
             self._dev[key] = imgproc.undistort_maps_device(self.cam1.K, self.cam1.D, self.cam1.xy, device=i1.device)
         mxy, ma = self._dev[key]
         out = imgproc.remap_fixed_bilinear(i1, mxy, ma)
-        return out.cpu().numpy() if was_np else out
+        return hostio.to_host(out) if was_np else out
 
     def distort_depth(self, depth):
         raise NotImplementedError("Stereo.distort_depth ('OOM warning and very slow' in the reference, "
@@ -278,41 +278,42 @@ class Stereo:
                                      bool(self.translation_rectify_img), 1.0 * self.baseline * self.K[0, 0],
                                      self.get_max_depth())
 
-    def _finish(self, result, i1, was_np, return_unrectify_depth, sgbm=None):
-        import torch
-        if return_unrectify_depth:
-            result.update(unrectify_depth=self.unrectify_depth(result["rectify_depth"]),
-                          undistort_img1=self.undistort_img(i1))
-        if was_np:
-            result = {k: v.cpu().numpy() if isinstance(v, torch.Tensor) else v for k, v in result.items()}
-            if sgbm is not None:
-                sgbm.status()  # the D2H copies above synchronised: surface device-side timeouts at no extra cost
-        return result
-
     def get_depth(self, img1, img2, return_unrectify_depth=True, return_distort_depth=False):
         """Return dict: rectify_img1, rectify_depth, disparity, rectify_img2 (+ unrectify_depth,
-        undistort_img1). Depth unit is m; 0 = invalid."""
+        undistort_img1). Depth unit is m; 0 = invalid.  ndarray inputs give ndarray results (each result starts
+        its way to the host as soon as its kernel is queued, hostio.Sink); device tensors stay on the device."""
         import torch
         assert hasattr(self, "stereo_matching"), "Please stereo.set_stereo_matching(stereo_matching)"
         if return_distort_depth:
             self.distort_depth(None)
         i1, was_np = self._to_dev(self._get_img(img1))
         i2, _ = self._to_dev(self._get_img(img2))
-        rectify_img1, rectify_img2 = self.rectify(i1, i2)
-        tb = self._tables(i1.device)
+        sink = hostio.Sink(i1.device) if was_np else None
         result = {}
+
+        def emit(**tensors):
+            result.update(tensors)
+            if sink is not None:
+                for k, t in tensors.items():
+                    sink.send(k, t)
+
+        rectify_img1, rectify_img2 = self.rectify(i1, i2)
+        emit(rectify_img1=rectify_img1, rectify_img2=rectify_img2)
+        if return_unrectify_depth:
+            emit(undistort_img1=self.undistort_img(i1))  # independent of the matcher: its copy hides under SGBM
+        tb = self._tables(i1.device)
+        plugin = self.stereo_matching
         sm = self._sgbm_full_res(rectify_img1.shape[:2])
         if sm is not None:
             disp16, _ = sm.compute_disp16(rectify_img1, rectify_img2)
             disparity, rectify_depth = self._fused_depth(sm, disp16, tb)
         else:
-            plugin = self.stereo_matching
             if isinstance(plugin, SemiGlobalBlockMatching):  # downsizing SGBM: stays on the GPU
                 disparity = plugin(rectify_img1, rectify_img2)
             else:  # foreign plugin: the reference's contract is NumPy in, NumPy (or dict) out
-                disparity = plugin(rectify_img1.cpu().numpy(), rectify_img2.cpu().numpy())
+                disparity = plugin(*hostio.to_host(rectify_img1, rectify_img2))
             if isinstance(disparity, dict):
-                result.update(disparity)
+                result.update({k: v for k, v in disparity.items() if k != "disparity"})
                 disparity = disparity["disparity"]
             if self.translation_rectify_img:
                 disparity += self.min_disparity  # in place, on the plugin's own array like :510-511
@@ -320,11 +321,14 @@ class Stereo:
                 disparity = torch.from_numpy(np.ascontiguousarray(disparity)).to(i1.device)
             disparity = tb["mask"].to(torch.bool) * disparity
             rectify_depth = self.disparity_to_depth(disparity)
-        result.update(rectify_img1=rectify_img1, rectify_depth=rectify_depth, disparity=disparity,
-                      rectify_img2=rectify_img2)
-        plugin = self.stereo_matching
-        return self._finish(result, i1, was_np, return_unrectify_depth,
-                            plugin.stereo_sgbm if isinstance(plugin, SemiGlobalBlockMatching) else None)
+        emit(disparity=disparity, rectify_depth=rectify_depth)
+        if return_unrectify_depth:
+            emit(unrectify_depth=self.unrectify_depth(rectify_depth))
+        if sink is not None:
+            result.update(sink.collect())
+            if isinstance(plugin, SemiGlobalBlockMatching):
+                plugin.stereo_sgbm.status()  # collect() synchronised: surface device-side timeouts at no extra cost
+        return result
 
     def get_depth_batch(self, imgs1, imgs2, return_unrectify_depth=True):
         """``get_depth`` for ``n`` pairs of the same rig at once: ``imgs1`` / ``imgs2`` are ``(n, h, w, 3)``
@@ -352,4 +356,9 @@ class Stereo:
         disparity, rectify_depth = self._fused_depth(sm, sm.stereo_sgbm.compute(rectify_img1, rectify_img2), tb)
         result = dict(rectify_img1=rectify_img1, rectify_depth=rectify_depth, disparity=disparity,
                       rectify_img2=rectify_img2)
-        return self._finish(result, i1, was_np, return_unrectify_depth, sm.stereo_sgbm)
+        if return_unrectify_depth:
+            result.update(unrectify_depth=self.unrectify_depth(rectify_depth), undistort_img1=self.undistort_img(i1))
+        if was_np:
+            result = dict(zip(result, hostio.to_host(*result.values())))
+            sm.stereo_sgbm.status()  # to_host synchronised: surface device-side timeouts at no extra cost
+        return result

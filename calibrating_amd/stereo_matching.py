@@ -8,7 +8,7 @@ stereo_camera.py:506-509).
 """
 import numpy as np
 
-from . import resize as _resize
+from . import hostio, resize as _resize
 from .sgbm import MODE_SGBM, StereoSGBM_create
 
 
@@ -72,4 +72,4 @@ class SemiGlobalBlockMatching(MetaStereoMatching):
         sdisparity = sdisp16.to(torch.float32).clamp_(min=0)
         sdisparity[sdisparity < self.stereo_sgbm.getMinDisparity() * 16] = 0
         disparity = _resize.resize(sdisparity / 16.0, (h, w)) * w / sw
-        return disparity.cpu().numpy() if is_np else disparity
+        return hostio.to_host(disparity) if is_np else disparity

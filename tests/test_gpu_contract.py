@@ -182,3 +182,35 @@ def test_u7_modes_agree_without_overflow(oracle):
             m = ca.StereoSGBM_create(**p)
             m.set_option("saturate", sat)
             assert np.array_equal(m.compute(l, r), want)
+
+
+def test_numpy_results_are_owned_by_the_caller():
+    """Ownership at the NumPy surface (every stage returns a freshly allocated array): a result keeps its
+    values when later calls run, is writable, and the page-locked hand-over returns the same values as plain copies."""
+    from calibrating_amd import hostio
+    W, H = 320, 240
+    stereo = ca.Stereo.load(synthetic.rig(W, H))
+    cfg = dict(max_size=W, minDisparity=0, numDisparities=32, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1)
+    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=3.5)
+    a1, a2 = synthetic.scene_pair(3, W, H, 3)
+    b1, b2 = synthetic.scene_pair(4, W, H, 3)
+    first = stereo.get_depth(a1, a2)
+    kept = {k: v.copy() for k, v in first.items()}
+    for _ in range(3):
+        other = stereo.get_depth(b1, b2)
+    assert not np.array_equal(other["disparity"], first["disparity"])
+    for k, v in first.items():
+        assert isinstance(v, np.ndarray) and v.flags.writeable and np.array_equal(v, kept[k]), k
+    first["rectify_depth"][:] = -1  # the caller may scribble on its result
+    assert np.array_equal(stereo.get_depth(a1, a2)["rectify_depth"], kept["rectify_depth"])
+    try:
+        hostio.PINNED = False
+        plain = stereo.get_depth(a1, a2)
+    finally:
+        hostio.PINNED = True
+    assert plain.keys() == kept.keys()
+    for k in kept:
+        assert np.array_equal(plain[k], kept[k]), k
+    many = stereo.get_depth_batch(np.stack([a1, b1]), np.stack([a2, b2]))
+    for k in kept:
+        assert np.array_equal(many[k][0], kept[k]), k

@@ -1,0 +1,31 @@
+"""The drop-in call as the reference's users make it: Stereo.get_depth(ndarray, ndarray) -> dict of ndarrays, one pair
+per call.  Wall time per call at 1080p and VGA, and where it goes."""
+import sys, os, time, json, cProfile, pstats, io
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import calibrating_amd as ca
+from calibrating_amd import synthetic
+res = {}
+for tag, W, H, D in (("1080p_d128", 1920, 1080, 128), ("vga_d64", 640, 480, 64)):
+    stereo = ca.Stereo.load(synthetic.rig(W, H))
+    cfg = dict(max_size=max(W, H), minDisparity=0, numDisparities=D, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+               uniquenessRatio=10, speckleWindowSize=100, speckleRange=2)
+    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=3.5)
+    i1, i2 = synthetic.scene_pair(9, W, H, 3)
+    for _ in range(3): out = stereo.get_depth(i1, i2)
+    t0 = time.perf_counter()
+    for _ in range(20): out = stereo.get_depth(i1, i2)
+    res[tag + "_numpy_in_out_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    res[tag + "_output_MB"] = sum(v.nbytes for v in out.values() if isinstance(v, np.ndarray)) / 1e6
+    t1, t2 = torch.from_numpy(i1).cuda(), torch.from_numpy(i2).cuda()
+    for _ in range(3): stereo.get_depth(t1, t2)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): stereo.get_depth(t1, t2)
+    torch.cuda.synchronize(); res[tag + "_device_resident_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    if tag.startswith("1080p") and "--profile" in sys.argv:
+        pr = cProfile.Profile(); pr.enable()
+        for _ in range(10): stereo.get_depth(i1, i2)
+        pr.disable(); s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(12); print(s.getvalue()[:3500])
+print(json.dumps({k: round(v, 3) for k, v in res.items()}, indent=1))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/numpy_latency.json", "w"), indent=1)
