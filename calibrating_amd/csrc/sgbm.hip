@@ -635,13 +635,16 @@ namespace camd {
 // MODE_SGBM_3WAY: rows of the final raw disparity come from the stripe that owns them
 __global__ __launch_bounds__(256) void k_gather_stripes(const int16_t* __restrict__ rawv, size_t rawv_stride_e,
                                                         int16_t* __restrict__ raw, size_t raw_stride_e, int W, int H,
-                                                        int stripe_sz, CostRanges cr)
+                                                        int stripe_sz, CostRanges cr, const uint32_t* __restrict__ err,
+                                                        int invalid)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, pair = blockIdx.z;
     if (x >= W) return;
     const int s = min(y / stripe_sz, cr.n - 1);
+    // a band pass that gave up waiting (sgbm_band.hpp) must not hand back plausible garbage: like k_lrcheck
+    const bool bad = err && *err;
     raw[(size_t)pair * raw_stride_e + (size_t)y * W + x] =
-        rawv[(size_t)(pair * cr.n + s) * rawv_stride_e + (size_t)(y - cr.start[s]) * W + x];
+        bad ? (int16_t)invalid : rawv[(size_t)(pair * cr.n + s) * rawv_stride_e + (size_t)(y - cr.start[s]) * W + x];
 }
 
 
@@ -803,6 +806,14 @@ static int auto_concurrent_pairs(const Geom& g, bool band_ok, int max_batch)
     return cap;
 }
 
+// The band passes are instantiated for 16 lanes x {1,2} vectors and 8 lanes x 1 vector per pixel; their inline
+// winner-take-all (not used by MODE_SGBM_3WAY, which decides its winners in k_wta) covers uniquenessRatio <= 99.
+static bool band_supported(const Geom& g)
+{
+    const bool shape = g.W1 > 0 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    return shape && (g.mode == CAMD_MODE_SGBM_3WAY || g.uniq <= 99);
+}
+
 // ndirs directions in one launch (ndirs > 1 only with FIRST: each direction writes its own volume)
 template <bool FIRST>
 static int launch_scan(const camd_sgbm* h, const int (*dirs)[2], int ndirs, uint16_t* S, size_t dir_stride,
@@ -863,11 +874,12 @@ static int launch_wta(const camd_sgbm* h, const uint16_t* S, int nvol, size_t di
     return CAMD_OK;
 }
 
-// one band-wavefront pass over `batch` pairs (sgbm_band.hpp): full = H, V, Dg, A of sweep (sx, sy);
-// !full = the row-parallel H-only pass
-static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int batch, hipStream_t st, bool diag = true)
+// one band-wavefront pass over `batch` (virtual) pairs (sgbm_band.hpp): full = H, V, Dg, A of sweep (sx, sy);
+// !full = the row-parallel H-only pass.  mode 0 writes S, 1 adds to S, 2 reads S and decides the winners.
+static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int batch, hipStream_t st, bool diag = true,
+                       bool tie8 = false)
 {
-    const Geom& g = h->g;
+    const Geom& g = h->ga;
     BandArgs a;
     a.C = h->C; a.S = h->S; a.E = h->E; a.flags = h->flags; a.ticket = h->ticket; a.err = h->err;
     a.keys = h->keys; a.d1 = h->d1; a.vol_stride = h->vol_elems; a.erec_stride = h->erec_stride;
@@ -892,7 +904,19 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     else if (full && mode == 2 && diag) CAMD_BAND_SHAPE(true, 2, true);
     else if (full && mode == 0) CAMD_BAND_SHAPE(true, 0, false);
     else if (full && mode == 2) CAMD_BAND_SHAPE(true, 2, false);
+    else if (!full && mode == 2 && tie8) {
+#define CAMD_BAND_TIE(LN, NVV)                                                                                  \
+    do {                                                                                                        \
+        if (pad) hipLaunchKernelGGL((k_band<LN, NVV, false, 2, true, true, true>), grid, block, 0, st, a, g);   \
+        else hipLaunchKernelGGL((k_band<LN, NVV, false, 2, false, true, true>), grid, block, 0, st, a, g);      \
+    } while (0)
+        if (g.lanes == 16 && g.nv == 1) CAMD_BAND_TIE(16, 1);
+        else if (g.lanes == 16) CAMD_BAND_TIE(16, 2);
+        else CAMD_BAND_TIE(8, 1);
+#undef CAMD_BAND_TIE
+    }
     else if (!full && mode == 2) CAMD_BAND_SHAPE(false, 2, true);
+    else if (!full && mode == 1) CAMD_BAND_SHAPE(false, 1, true);
     else { set_error("band pass (full %d, mode %d) not instantiated", (int)full, mode); return CAMD_ERR_UNSUPPORTED; }
 #undef CAMD_BAND_SHAPE
 #undef CAMD_BAND
@@ -921,12 +945,12 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     size_t total = (size_t)max_batch * (2 * cr.n * vol + raw);
     if (way3) total += (size_t)max_batch * cr.n * align_up((size_t)vrows * width * 2, 256);
     if (g.speckleWindowSize > 0) total += speckle_ws_bytes(width, height, max_batch);
-    const bool band_ok = !way3 && w1 > 0 && g.uniq <= 99 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    const bool band_ok = band_supported(g);
     if (band_ok) {
         const int R = BAND_THREADS / g.lanes;
-        size_t nb = (size_t)div_up(height, R);
-        total += (size_t)max_batch * nb * (band_erec_stride(g.W1, g.lanes, g.nv) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
-        total += (size_t)max_batch * height * width * 6 + 8;
+        size_t nb = (size_t)div_up(vrows, R);
+        total += (size_t)max_batch * cr.n * nb * (band_erec_stride(g.W1, g.lanes, g.nv) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
+        total += (size_t)max_batch * cr.n * vrows * width * 6 + 8;
     }
     if (!way3) total += (size_t)g.npaths * auto_concurrent_pairs(g, band_ok, max_batch) * vol;  // per-direction volumes (latency path)
     return total;
@@ -974,19 +998,18 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     if (e == hipSuccess) e = hipMalloc((void**)&h->raw, (size_t)max_batch * raw_e * 2);
     size_t sws = speckle_ws_bytes(width, height, max_batch);
     if (e == hipSuccess && g.speckleWindowSize > 0) e = hipMalloc(&h->speckle_ws, sws);
-    // band-wavefront path: instantiated for 16 lanes x {1,2} vectors and 8 lanes x 1 vector
-    h->band_ok = !way3 && w1 > 0 && g.uniq <= 99 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    h->band_ok = band_supported(g);
     h->path = 0;
     h->saturate = 1;
     h->epoch = 0;
     if (h->band_ok) {
         const int R = BAND_THREADS / g.lanes;
-        h->nbands = div_up(height, R);
+        h->nbands = div_up(vrows, R);  // bands of one (virtual) pair
         h->nchunks = div_up(g.W1, BAND_CHUNK);
         h->erec_stride = band_erec_stride(g.W1, g.lanes, g.nv);
-        size_t nflags = (size_t)max_batch * h->nbands * h->nchunks;
-        size_t npix = (size_t)max_batch * height * width;
-        if (e == hipSuccess) e = hipMalloc((void**)&h->E, (size_t)max_batch * h->nbands * h->erec_stride * 8);
+        size_t nflags = nvol * h->nbands * h->nchunks;
+        size_t npix = nvol * vrows * width;  // the winner-take-all state of every (virtual) pair
+        if (e == hipSuccess) e = hipMalloc((void**)&h->E, nvol * h->nbands * h->erec_stride * 8);
         if (e == hipSuccess) e = hipMalloc((void**)&h->flags, nflags * 4);
         if (e == hipSuccess) e = hipMalloc((void**)&h->ticket, 8);
         if (e == hipSuccess) e = hipMalloc((void**)&h->keys, npix * 4);
@@ -1253,15 +1276,33 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         if (batch * pair_work(g) <= auto_concurrent_limit(g) || !h->band_ok) path = CAMD_PATH_CONCURRENT;
         else path = CAMD_PATH_BAND;
     }
+    if (way3 && path != CAMD_PATH_SCAN) path = CAMD_PATH_BAND;  // (no per-direction volumes for the stripes)
     if (path == CAMD_PATH_BAND && !h->band_ok) path = CAMD_PATH_SCAN;
-    if (way3) path = CAMD_PATH_SCAN;  // three line scans per stripe (the stripes are independent "virtual pairs")
     // the per-direction volumes were sized in create / set_option: a larger batch takes the next best path
     if (path == CAMD_PATH_CONCURRENT && batch > mcap) path = h->band_ok ? CAMD_PATH_BAND : CAMD_PATH_SCAN;
     const bool band = path == CAMD_PATH_BAND;
     const bool multi = path == CAMD_PATH_CONCURRENT;
     const size_t dir_stride = (size_t)mcap * h->vol_elems;
     MARK(ST_SCAN);
-    if (band) {
+    // 3WAY decides its winners inside the last band pass when that pass knows the tie rule in force: cv2's 8-slot
+    // rule for D % 8 == 0, or the scalar build's "smallest d" (the ordinary rule); otherwise k_wta does it afterwards
+    const bool way3_inline = way3 && (h->way3_simd_lanes == 1 || g.D % 8 == 0);
+    if (band && way3) {
+        // the stripes are independent "virtual pairs": -> and v in one band pass, <- by the row-parallel pass
+        const Geom& ga = h->ga;
+        if (way3_inline) {
+            size_t npix = (size_t)vbatch * ga.H * ga.W;
+            hipLaunchKernelGGL(k_wta_init, dim3(div_up((long long)npix, 256)), dim3(256), 0, st, h->keys, h->d1, npix,
+                               (g.minD - 1) * 16);
+            CAMD_LAUNCH_CHECK();
+        }
+        int rc = launch_band(h, +1, +1, true, 0, vbatch, st, false);
+        if (rc != CAMD_OK) return rc;
+        MARK(ST_SCAN2);
+        rc = way3_inline ? launch_band(h, -1, +1, false, 2, vbatch, st, true, h->way3_simd_lanes == 8)
+                         : launch_band(h, -1, +1, false, 1, vbatch, st);
+        if (rc != CAMD_OK) return rc;
+    } else if (band) {
         // fused passes: every pass reads C once and touches S once for up to four directions
         size_t npix = (size_t)batch * g.H * g.W;
         hipLaunchKernelGGL(k_wta_init, dim3(div_up((long long)npix, 256)), dim3(256), 0, st, h->keys, h->d1, npix,
@@ -1292,7 +1333,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     }
 
     MARK(ST_WTA);
-    if (band) {
+    if (band && !way3) {
         hipLaunchKernelGGL(k_lrcheck, dim3(div_up(g.W, 256), g.H, batch), dim3(256), 0, st, h->d1, h->keys, h->raw,
                            (size_t)g.W, raw_stride, g, h->err);
         CAMD_LAUNCH_CHECK();
@@ -1300,11 +1341,18 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     } else if (way3) {
         // winner-take-all + LR check per stripe row, then every image row is taken from the stripe that owns it
         const size_t rawv_stride = align_up((size_t)h->ga.H * g.W * 2, 256) / 2;
-        int rc = launch_wta(h, h->S, 1, 0, h->rawv, (size_t)g.W, rawv_stride, vbatch, st);
-        if (rc != CAMD_OK) return rc;
+        if (band && way3_inline) {
+            hipLaunchKernelGGL(k_lrcheck, dim3(div_up(g.W, 256), h->ga.H, vbatch), dim3(256), 0, st, h->d1, h->keys,
+                               h->rawv, (size_t)g.W, rawv_stride, h->ga, h->err);
+            CAMD_LAUNCH_CHECK();
+        } else {
+            int rc = launch_wta(h, h->S, 1, 0, h->rawv, (size_t)g.W, rawv_stride, vbatch, st);
+            if (rc != CAMD_OK) return rc;
+        }
         hipLaunchKernelGGL(k_gather_stripes, dim3(div_up(g.W, 256), g.H, batch), dim3(256), 0, st, h->rawv, rawv_stride,
-                           h->raw, raw_stride, g.W, g.H, h->stripe_sz, h->cr);
+                           h->raw, raw_stride, g.W, g.H, h->stripe_sz, h->cr, band ? h->err : nullptr, (g.minD - 1) * 16);
         CAMD_LAUNCH_CHECK();
+        if (band) CAMD_HIP(hipMemcpyAsync(h->err_host, h->err, 4, hipMemcpyDeviceToHost, st));
     } else {
         int rc = multi ? launch_wta(h, h->Smulti, g.npaths, dir_stride, h->raw, (size_t)g.W, raw_stride, batch, st)
                        : launch_wta(h, h->S, 1, 0, h->raw, (size_t)g.W, raw_stride, batch, st);

@@ -108,7 +108,11 @@ static inline size_t band_erec_stride(int W1, int lanes, int nv) { return (size_
 // dpk[k] = the two disparities of register k, packed (d | d+1 << 16).
 static constexpr uint32_t WTA_NONE = 0xffffffffu;
 
-template <int LANES, int NV>
+// TIE8: MODE_SGBM_3WAY's winner among equal totals as OpenCV's CV_SIMD build picks it (k_wta, oracle way3_winner),
+// for D % 8 == 0: disparities are scanned 8 at a time, each of the 8 lane slots keeps the LAST d attaining the
+// minimum, the winner is the smallest of those positions.  With a single minimum that is the ordinary winner, so the
+// rule is only evaluated when some pixel of the wave has its first and last minimum at different d.
+template <int LANES, int NV, bool TIE8 = false>
 __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const uint32_t (&dpk)[4 * NV], uint4* wS,
                                               const Geom& g, int grp, int li, int t, bool act, uint32_t& cap_key,
                                               uint32_t& cap_nb)
@@ -122,7 +126,35 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const
         key = min(key, __builtin_amdgcn_perm(s[k], dpk[k], 0x07060302u));  // S.hi << 16 | d + 1
     }
     key = group_min_u32_full<LANES>(key);
-    const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
+    const int minS = (int)(key >> 16);
+    int best = (int)(key & 0xffffu);
+    if (TIE8) {
+        uint32_t kl = 0xffffffffu;  // (S << 16 | 0xffff - d) minimum: smallest S, then LARGEST d
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const uint32_t nd = ~dpk[k];
+            kl = min(kl, __builtin_amdgcn_perm(s[k], nd, 0x05040100u));
+            kl = min(kl, __builtin_amdgcn_perm(s[k], nd, 0x07060302u));
+        }
+        kl = group_min_u32_full<LANES>(kl);
+        if (__any((int)(0xffffu - (kl & 0xffffu)) != best)) {
+            uint32_t pos = 0xffffffffu;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                uint32_t last = 0;  // 1 + the largest d of slot e (in this lane) whose total is the minimum
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const uint32_t val = (e & 1) ? (s[4 * v + e / 2] >> 16) : (s[4 * v + e / 2] & 0xffffu);
+                    const uint32_t d = (e & 1) ? (dpk[4 * v + e / 2] >> 16) : (dpk[4 * v + e / 2] & 0xffffu);
+                    if ((int)d < g.D && (int)val == minS) last = d + 1;
+                }
+                last = group_max_u32<LANES>(last);
+                if (last) pos = min(pos, last - 1);
+            }
+            best = (int)pos;
+            key = ((uint32_t)minS << 16) | pos;
+        }
+    }
     // park S so that S[best-1], S[best+1] can be picked without a select tree
 #pragma unroll
     for (int v = 0; v < NV; v++)
@@ -191,7 +223,7 @@ __device__ __forceinline__ void band_wta_flush(const BandArgs& a, const Geom& g,
 // FULL: H, V, Dg, A of sweep (sx, sy), skew 2.  !FULL: H of sweep sx only (rows independent).
 // MODE: 0 = first pass (S written), 2 = final (S read, WTA; S stored only for the parity hook)
 // DIAG = false (MODE_HH4): the two diagonal directions are left out (their slots travel as zeros)
-template <int LANES, int NV, bool FULL, int MODE, bool PAD, bool DIAG = true>
+template <int LANES, int NV, bool FULL, int MODE, bool PAD, bool DIAG = true, bool TIE8 = false>
 __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a, Geom g)
 {
     constexpr int NR = 4 * NV;
@@ -475,7 +507,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
 #pragma unroll
                     for (int v = 0; v < NV; v++) sp[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
                 }
-                if (MODE == 2) band_wta_step<LANES, NV>(s, dpk, wS, g, grp, li, t, true, cap_key, cap_nb);
+                if (MODE == 2) band_wta_step<LANES, NV, TIE8>(s, dpk, wS, g, grp, li, t, true, cap_key, cap_nb);
             }
             if (MODE == 2 && ((t & (LANES - 1)) == LANES - 1 || t == nsteps - 1)) {
                 // lane li captured the pixel of step t - ((t mod LANES) - li)

@@ -191,13 +191,15 @@ def test_sgbm_full_size_rows_vs_oracle(oracle):
     (68, 160, 16, 1, 0, 0, dict(uniquenessRatio=0)),   # blockSize 0 -> radius 1 in this mode; uniqueness test off
     (97, 330, 200, 1, 5, 0, {}),                      # D > 128: two 8-groups per lane
 ])
-def test_sgbm_3way_vs_oracle(oracle, H, W, D, cn, bs, minD, extra):
+@pytest.mark.parametrize("path", [0, 1])  # 0: two band passes where the shape allows, 1: three line scans
+def test_sgbm_3way_vs_oracle(oracle, H, W, D, cn, bs, minD, extra, path):
     left, right = synthetic.rectified_pair(seed=21, H=H, W=W, D=max(D, 8), cn=cn)
     b = bs if bs > 0 else 3
     p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=8 * cn * b * b, P2=32 * cn * b * b, disp12MaxDiff=1,
              uniquenessRatio=10, mode=ca.MODE_SGBM_3WAY)
     p.update(extra)
     m = ca.StereoSGBM_create(**p)
+    m.set_option("path", path)
     got = m.compute(left, right)
     want = oracle.sgbm_compute(left, right, **p)
     assert np.array_equal(got, want), "%d of %d pixels differ" % ((got != want).sum(), got.size)
@@ -214,11 +216,12 @@ def test_sgbm_3way_tie_rule(oracle, lanes):
     borders do not break the tie): the winner is decided by the tie rule alone -- cv2's SIMD lane-slot rule (default:
     the last disparity of each of the 8 slots, then the smallest of those = D - 8 for D % 8 == 0) or the scalar build's
     smallest d.  D = 50 exercises the SIMD region [0, 48) + scalar tail {48, 49}."""
-    H, W = 72, 220
-    flat = np.full((H, W), 15, np.uint8)
+    H = 72
     try:
         oracle.set_switches(way3_simd_lanes=lanes)
-        for D, winner8 in ((64, 56), (50, 40)):
+        for D, winner8 in ((64, 56), (50, 40), (256, 248)):  # (256: two 8-groups per lane in the band pass)
+            W = D + 156
+            flat = np.full((H, W), 15, np.uint8)
             p = dict(minDisparity=0, numDisparities=D, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, uniquenessRatio=0,
                      mode=ca.MODE_SGBM_3WAY)
             m = ca.StereoSGBM_create(**p)
@@ -230,6 +233,27 @@ def test_sgbm_3way_tie_rule(oracle, lanes):
             assert raw[H // 2, W - 1] == (winner8 * 16 if lanes == 8 else 0), (lanes, D, raw[H // 2, W - 1])
     finally:
         oracle.set_switches()
+
+
+@pytest.mark.parametrize("D", [32, 128, 200])
+def test_sgbm_3way_ties_next_to_texture(oracle, D):
+    """Flat blocks (every total ties) tiled into a textured pair: waves that meet both kinds of pixel evaluate the
+    tie rule for some lanes only, and plateaus inside a block tie between a few disparities rather than all."""
+    H, W = 96, D + 150
+    left, right = synthetic.rectified_pair(seed=5, H=H, W=W, D=D, cn=1)
+    left, right = left.copy(), right.copy()
+    for img in (left, right):
+        img[10:40, D + 10:D + 90] = 15
+        img[50:90:2, :] = 15                 # flat rows between textured ones
+        img[:, D + 100:D + 130] //= 64       # 4 grey levels: short plateaus
+    p = dict(minDisparity=0, numDisparities=D, blockSize=3, P1=20, P2=80, disp12MaxDiff=1, uniquenessRatio=0,
+             mode=ca.MODE_SGBM_3WAY)
+    want = oracle.sgbm_compute(left, right, **p)
+    for path in (0, 1):
+        m = ca.StereoSGBM_create(**p)
+        m.set_option("path", path)
+        got = m.compute(left, right)
+        assert np.array_equal(got, want), (path, (got != want).sum())
 
 
 def test_sgbm_3way_refuses_tiny_images():

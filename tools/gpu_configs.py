@@ -16,6 +16,19 @@ def timeit(fn, reps=3, warm=1):
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
 
+# ---- C2 geometry, every aggregation mode of cv2.StereoSGBM (the bench line covers MODE_SGBM and MODE_HH in flight)
+for mode, name in ((0, "sgbm"), (1, "hh"), (3, "hh4"), (2, "3way")):
+    P = dict(minDisparity=0, numDisparities=128, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1, uniquenessRatio=10, mode=mode)
+    nb = 64
+    L, R = synthetic.rectified_batch_torch(11, nb, 1080, 1920, 128, 3, dev)
+    m = ca.StereoSGBM_create(**P)
+    out = torch.empty((nb, 1080, 1920), dtype=torch.int16, device=dev)
+    dt = timeit(lambda: m.compute(L, R, out=out), reps=3)
+    m.status()
+    res["C2_1080p_d128_rgb_%s_single_stream_pairs_per_s" % name] = nb / dt
+    del m, L, R, out
+    torch.cuda.empty_cache()
+
 # ---- C4: 4K, D=256, gray, LDS-tiled aggregation on one GPU
 for mode, name in ((0, "sgbm"), (1, "hh")):
     P = dict(minDisparity=0, numDisparities=256, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, uniquenessRatio=10, mode=mode)
