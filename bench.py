@@ -214,27 +214,6 @@ def pcie_inclusive(matcher, left, right, out, steps, streams=()):
                 note="pinned host buffers, H2D + compute + D2H overlapped on 3 streams, %d steps of %d pairs" % (steps, nb))
 
 
-def bind_near_gpu(index):
-    """Pin this process to the CPUs of the GPU's NUMA node (sysfs local_cpulist of its PCI function): pinned host
-    buffers then come from the memory next to the GPU's PCIe root, and with N ranks every rank stays beside its own
-    GPU.  Returns the cpulist string, or None when sysfs does not tell."""
-    try:
-        import torch
-        pr = torch.cuda.get_device_properties(index)
-        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-        cpulist = open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip()
-        cpus = set()
-        for part in cpulist.split(","):
-            lo, _, hi = part.partition("-")
-            cpus.update(range(int(lo), int(hi or lo) + 1))
-        if cpus:
-            os.sched_setaffinity(0, cpus)
-            return cpulist
-    except Exception:
-        pass
-    return None
-
-
 def self_launch(a):
     """--gpus N > 1 without a launcher: run N ranks of this script under torch.distributed.run."""
     import torch
@@ -269,7 +248,8 @@ def main():
         sys.exit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cpus_near_gpu = bind_near_gpu(local_rank)
+    from calibrating_amd import hostio
+    cpus_near_gpu = hostio.bind_near_gpu(local_rank)
     # CAMD_BENCH_FORCE_DIST=1 exercises the RCCL path (init, table broadcast, barrier, reductions) with a
     # single rank, e.g. under `python -m torch.distributed.run --nproc-per-node 1`
     distributed = world > 1 or (os.environ.get("CAMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)

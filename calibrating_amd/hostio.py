@@ -70,3 +70,26 @@ class Sink:
         self.side.synchronize()
         self.main.synchronize()
         return {k: h.numpy() for k, h in self.staged.items()}
+
+
+def bind_near_gpu(index=0):
+    """Pin this process to the CPUs of the GPU's NUMA node (sysfs ``local_cpulist`` of its PCI function): page-locked
+    blocks then come from the memory next to the GPU's PCIe root, and with one process per GPU every rank stays beside
+    its own device.  Opt-in (a library does not change its host's affinity by itself); ``bench.py`` calls it.
+    Returns the cpulist string, or None when sysfs does not tell."""
+    import os
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        cpulist = open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip()
+        cpus = set()
+        for part in cpulist.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return cpulist
+    except Exception:
+        pass
+    return None

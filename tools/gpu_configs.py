@@ -32,7 +32,7 @@ for mode, name in ((0, "sgbm"), (1, "hh"), (3, "hh4"), (2, "3way")):
 # ---- C4: 4K, D=256, gray, LDS-tiled aggregation on one GPU
 for mode, name in ((0, "sgbm"), (1, "hh")):
     P = dict(minDisparity=0, numDisparities=256, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, uniquenessRatio=10, mode=mode)
-    nb = 6
+    nb = 16  # (6 pairs: 172 pairs/s, 12: 196, 16: 208, 20: 200 -- the band wavefront of a pair fills slowly at 78 bands)
     L, R = synthetic.rectified_batch_torch(7, nb, 2160, 3840, 256, 1, dev)
     m = ca.StereoSGBM_create(**P)
     out = torch.empty((nb, 2160, 3840), dtype=torch.int16, device=dev)

@@ -4,8 +4,10 @@ import sys, os, time, json, cProfile, pstats, io
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import calibrating_amd as ca
-from calibrating_amd import synthetic
+from calibrating_amd import synthetic, hostio
 res = {}
+if "--bind" in sys.argv:
+    res["bound_to_cpus"] = hostio.bind_near_gpu(0)
 for tag, W, H, D in (("1080p_d128", 1920, 1080, 128), ("vga_d64", 640, 480, 64)):
     stereo = ca.Stereo.load(synthetic.rig(W, H))
     cfg = dict(max_size=max(W, H), minDisparity=0, numDisparities=D, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
@@ -26,6 +28,6 @@ for tag, W, H, D in (("1080p_d128", 1920, 1080, 128), ("vga_d64", 640, 480, 64))
         pr = cProfile.Profile(); pr.enable()
         for _ in range(10): stereo.get_depth(i1, i2)
         pr.disable(); s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(12); print(s.getvalue()[:3500])
-print(json.dumps({k: round(v, 3) for k, v in res.items()}, indent=1))
+print(json.dumps({k: round(v, 3) if isinstance(v, float) else v for k, v in res.items()}, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/numpy_latency.json", "w"), indent=1)
