@@ -36,8 +36,15 @@ namespace camd {
 
 // 7 compute waves + 1 helper wave = 8 waves per workgroup: two workgroups fill a CU's 16 wave slots at
 // <= 128 VGPRs (nine waves would leave room for only one)
-static constexpr int BAND_THREADS = 448;                 // compute threads
+#ifndef CAMD_BAND_COMPUTE_WAVES
+#define CAMD_BAND_COMPUTE_WAVES 7
+#endif
+#ifndef CAMD_BAND_HELPER_WAVE
+#define CAMD_BAND_HELPER_WAVE CAMD_BAND_COMPUTE_WAVES    // which wave of the workgroup is the helper (default: the last)
+#endif
+static constexpr int BAND_THREADS = 64 * CAMD_BAND_COMPUTE_WAVES;  // compute threads
 static constexpr int BAND_BLOCK = BAND_THREADS + 64;     // + one helper wave
+static constexpr int BAND_HELPER_WAVE = CAMD_BAND_HELPER_WAVE;
 static constexpr int BAND_RING = 4;                      // C/S prefetch ring (xi .. xi+3)
 #ifndef BAND_RING_ROWS
 #define BAND_RING_ROWS 4                                 // ... of the row-parallel (!FULL) pass
@@ -114,8 +121,8 @@ static constexpr uint32_t WTA_NONE = 0xffffffffu;
 // rule is only evaluated when some pixel of the wave has its first and last minimum at different d.
 template <int LANES, int NV, bool TIE8 = false>
 __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const uint32_t (&dpk)[4 * NV], uint4* wS,
-                                              const Geom& g, int grp, int li, int t, bool act, uint32_t& cap_key,
-                                              uint32_t& cap_nb)
+                                              const Geom& g, int ctid, int grp, int li, int t, bool act,
+                                              uint32_t& cap_key, uint32_t& cap_nb)
 {
     constexpr int NR = 4 * NV;
     // (1) minS and the smallest d attaining it: min over keys (S << 16 | d); padded d >= D hold 0x7FFF
@@ -158,7 +165,7 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const
     // park S so that S[best-1], S[best+1] can be picked without a select tree
 #pragma unroll
     for (int v = 0; v < NV; v++)
-        wS[threadIdx.x * NV + v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
+        wS[ctid * NV + v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
     // (2) uniqueness: S[d]*(100-u) < minS*100 for some |d-best| > 1
     //     <=>  min over those d of S[d]  <=  T = floor((minS*100 - 1) / (100-u)); the division by the launch
     //     constant 100-u is a multiply-high by floor(2^32/(100-u)) + 1, exact for numerators < 2^32/100
@@ -252,9 +259,14 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
     // pairs in flight a workgroup's upstream band is usually far ahead by the time it starts (the
     // dependency (pair, b-1) always holds an earlier ticket)
     const int band = ticket / a.npairs, pair = ticket % a.npairs;
-    const bool helper = threadIdx.x >= BAND_THREADS;               // wave-uniform
+    // roles: wave BAND_HELPER_WAVE is the helper, the others are compute waves numbered in wave order (ctid =
+    // compute thread index).  Which wave helps decides which SIMD carries one compute wave less (see
+    // tools/microtests/wave_simd_placement.hip)
+    const int wv = threadIdx.x >> 6;
+    const bool helper = wv == BAND_HELPER_WAVE;                    // wave-uniform
     if (!FULL && helper) return;
-    const int grp = threadIdx.x / LANES, li = threadIdx.x % LANES;
+    const int ctid = helper ? (int)(threadIdx.x & 63) : (((wv > BAND_HELPER_WAVE ? wv - 1 : wv) << 6) | (int)(threadIdx.x & 63));
+    const int grp = ctid / LANES, li = ctid % LANES;
     const int W1 = g.W1, H = g.H;
     const int row = band * R + grp;  // row index in sweep order
     const bool rvalid = !helper && row < H;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
     const uint32_t* Fin = a.flags + ((size_t)pair * a.nbands + (band > 0 ? band - 1 : 0)) * a.nchunks;
 
     // helper wave state: lane hl fetches column (batch*CPB + hl/LANES), lane-in-group hl%LANES
-    const int hl = threadIdx.x - BAND_THREADS;
+    const int hl = threadIdx.x & 63;
     unsigned long long pend[EVEC], pdl[2];
 #pragma unroll
     for (int k = 0; k < EVEC; k++) pend[k] = 0;
@@ -395,9 +407,9 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
             // slot 1 is what step 0 reads as "produced in step -1": the zero border state
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                xV[1][threadIdx.x * NV + v] = make_uint4(0u, 0u, 0u, 0u);
-                xD[1][threadIdx.x * NV + v] = make_uint4(0u, 0u, 0u, 0u);
-                xA[1][threadIdx.x * NV + v] = make_uint4(0u, 0u, 0u, 0u);
+                xV[1][ctid * NV + v] = make_uint4(0u, 0u, 0u, 0u);
+                xD[1][ctid * NV + v] = make_uint4(0u, 0u, 0u, 0u);
+                xA[1][ctid * NV + v] = make_uint4(0u, 0u, 0u, 0u);
             }
             if (li == 0) xdl[1][grp] = make_uint4(P2pk, P2pk, P2pk, 0u);
         }
@@ -453,9 +465,9 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
             if (FULL) {
                 const int rb = (u & 1) ^ 1;
                 if (grp > 0) {
-                    lds_vec(&xV[rb][(threadIdx.x - LANES) * NV], VS[u & 1]);
-                    lds_vec(&xD[rb][(threadIdx.x - LANES) * NV], DS[u & 3]);
-                    lds_vec(&xA[rb][(threadIdx.x - LANES) * NV], An);
+                    lds_vec(&xV[rb][(ctid - LANES) * NV], VS[u & 1]);
+                    lds_vec(&xD[rb][(ctid - LANES) * NV], DS[u & 3]);
+                    lds_vec(&xA[rb][(ctid - LANES) * NV], An);
                     const uint4 dl = xdl[rb][grp - 1];
                     dVs[u & 1] = dl.x;
                     dDs[u & 3] = dl.y;
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
 #pragma unroll
                     for (int v = 0; v < NV; v++) sp[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
                 }
-                if (MODE == 2) band_wta_step<LANES, NV, TIE8>(s, dpk, wS, g, grp, li, t, true, cap_key, cap_nb);
+                if (MODE == 2) band_wta_step<LANES, NV, TIE8>(s, dpk, wS, g, ctid, grp, li, t, true, cap_key, cap_nb);
             }
             if (MODE == 2 && ((t & (LANES - 1)) == LANES - 1 || t == nsteps - 1)) {
                 // lane li captured the pixel of step t - ((t mod LANES) - li)
@@ -518,9 +530,9 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
                 const int wb = u & 1;
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    xV[wb][threadIdx.x * NV + v] = make_uint4(LVo[4 * v], LVo[4 * v + 1], LVo[4 * v + 2], LVo[4 * v + 3]);
-                    xD[wb][threadIdx.x * NV + v] = make_uint4(LDo[4 * v], LDo[4 * v + 1], LDo[4 * v + 2], LDo[4 * v + 3]);
-                    xA[wb][threadIdx.x * NV + v] = make_uint4(LAo[4 * v], LAo[4 * v + 1], LAo[4 * v + 2], LAo[4 * v + 3]);
+                    xV[wb][ctid * NV + v] = make_uint4(LVo[4 * v], LVo[4 * v + 1], LVo[4 * v + 2], LVo[4 * v + 3]);
+                    xD[wb][ctid * NV + v] = make_uint4(LDo[4 * v], LDo[4 * v + 1], LDo[4 * v + 2], LDo[4 * v + 3]);
+                    xA[wb][ctid * NV + v] = make_uint4(LAo[4 * v], LAo[4 * v + 1], LAo[4 * v + 2], LAo[4 * v + 3]);
                 }
                 if (li == 0) xdl[wb][grp] = make_uint4(dVo, dDo, dAo, 0u);
                 if (producer && act) {
