@@ -352,6 +352,20 @@ def main():
             d3, _ = gpu_steps(m3, gl, gr, out, k2, 1)
             also["gray_%s_pairs_per_s" % a.mode] = nb * k2 / d3
             del m3, gl, gr
+            # the whole Stereo.get_depth path around the same matcher (rectify x2 -> SGBM -> disp_to_depth -> unrectify
+            # -> undistort) on a synthetic rig of the same size, one batch per call
+            torch.cuda.empty_cache()
+            stereo = ca.Stereo.load(synthetic.rig(a.width, a.height))
+            stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(params, max_size=max(a.width, a.height))),
+                                       max_depth=20.0)
+            stereo.get_depth_batch(left, right)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                stereo.get_depth_batch(left, right)
+            torch.cuda.synchronize()
+            also["get_depth_batch_pairs_per_s"] = nb * 3 / (time.perf_counter() - t0)
+            del stereo
 
     if rank == 0:
         b_alg, V = algorithmic_bytes_per_pair(a.width, a.height, a.disparities, a.channels)
