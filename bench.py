@@ -113,16 +113,25 @@ def cpu_baseline(a, params):
     base_l, base_r = synthetic.rectified_pair(seed=1234, H=hs, W=a.width, D=a.disparities, cn=a.channels)
     L = np.stack([np.roll(base_l, 17 * i, axis=0) for i in range(n)])  # distinct strips: vertical rolls
     R = np.stack([np.roll(base_r, 17 * i, axis=0) for i in range(n)])
+    # this leg runs on ALL host CPUs: lift the binding to the GPU's NUMA node (hostio.bind_near_gpu) while it lasts --
+    # OpenMP threads inherit the affinity of the thread that starts them
+    bound = os.sched_getaffinity(0)
+    try:
+        os.sched_setaffinity(0, range(ncpu))
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0))
     t0 = time.perf_counter()
     oracle.sgbm_compute_batch(L, R, nthreads=threads, **params)
     dt = time.perf_counter() - t0
+    os.sched_setaffinity(0, bound)
     pairs = n * hs / a.height
     return dict(value=pairs / dt, unit="pairs/s", cores=threads, host_cpu_count=ncpu, kind="port",
                 sample="%d strips of %dx%d (= %.2f pairs of %dx%d) D=%d cn=%d mode=%s, scalar C port "
-                       "oracle/sgbm_ref.c, %d OpenMP threads across strips (os.cpu_count() = %d), %.1f s; "
-                       "cv2 itself is not installed on this box"
+                       "oracle/sgbm_ref.c, %d OpenMP threads across strips on %d usable CPUs (os.cpu_count() = %d), "
+                       "%.1f s; cv2 itself is not installed on this box"
                        % (n, a.width, hs, pairs, a.width, a.height, a.disparities, a.channels, a.mode,
-                          threads, ncpu, dt))
+                          threads, usable, ncpu, dt))
 
 
 def gpu_steps(matcher, left, right, out, steps, warmup, distributed=False):
