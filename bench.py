@@ -124,9 +124,18 @@ def cpu_baseline(a, params):
     t0 = time.perf_counter()
     oracle.sgbm_compute_batch(L, R, nthreads=threads, **params)
     dt = time.perf_counter() - t0
+    # the port streams a volume per thread and is bound by host memory bandwidth long before it runs out of cores:
+    # a second, short sample on an eighth of the threads is reported beside the all-core figure
+    fewer = {}
+    if threads >= 16 and not a.cpu_pairs:
+        t8 = threads // 8
+        t1 = time.perf_counter()
+        oracle.sgbm_compute_batch(L[:t8], R[:t8], nthreads=t8, **params)
+        fewer = {str(t8): (t8 * hs / a.height) / (time.perf_counter() - t1)}
     os.sched_setaffinity(0, bound)
     pairs = n * hs / a.height
     return dict(value=pairs / dt, unit="pairs/s", cores=threads, host_cpu_count=ncpu, kind="port",
+                pairs_per_s_at_fewer_threads=fewer,
                 sample="%d strips of %dx%d (= %.2f pairs of %dx%d) D=%d cn=%d mode=%s, scalar C port "
                        "oracle/sgbm_ref.c, %d OpenMP threads across strips on %d usable CPUs (os.cpu_count() = %d), "
                        "%.1f s; cv2 itself is not installed on this box"
