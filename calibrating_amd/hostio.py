@@ -8,9 +8,11 @@ additionally moves each result on a side stream as soon as its kernel has been q
 results (the rectified images) run underneath the later kernels (SGBM).  At 1080p the ~60 MB a ``get_depth`` call
 returns cost more wall time through pageable copies than all of its kernels.
 
-``PINNED = False`` falls back to plain ``.cpu()`` copies (for hosts where page-locked memory is rationed).
+``PINNED = False`` falls back to plain ``.cpu()`` copies (for hosts where page-locked memory is rationed); calls that
+return more than ``PINNED_MAX_BYTES`` at once do so by themselves.
 """
 PINNED = True
+PINNED_MAX_BYTES = 1 << 30  # results larger than this in one call (big get_depth_batch calls) take plain copies
 
 _side_streams = {}
 
@@ -33,7 +35,7 @@ def _start(t):
 def to_host(*tensors):
     """ndarrays of CUDA tensors: all copies queued on the current stream, one synchronisation."""
     import torch
-    if not PINNED:
+    if not PINNED or sum(t.numel() * t.element_size() for t in tensors) > PINNED_MAX_BYTES:
         out = [t.cpu().numpy() for t in tensors]
     else:
         with torch.cuda.device(tensors[0].device):
