@@ -171,6 +171,28 @@ def test_sgbm_full_size_properties(mode):
     assert (np.abs(d1[v] / 16.0 - g[v]) < 1).mean() > 0.9
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sgbm_headline_config_whole_pair_vs_oracle(oracle, mode):
+    """The bench workload itself -- one whole 1920x1080 RGB pair, D=128, blockSize 5 -- bit for bit against the oracle
+    (a few seconds of scalar C per mode), through the band passes the throughput runs use (every row chunk of k_cost,
+    all 39 bands and their edge records) and through the AUTO path a single pair takes; then inside a batch of three
+    different pairs."""
+    D = 128
+    left, right = synthetic.rectified_pair(seed=1234, H=1080, W=1920, D=D, cn=3)
+    p = _params(3, D, 5, 0, mode)
+    want = oracle.sgbm_compute(left, right, **p)
+    for path in (2, 0):
+        m = StereoSGBM_create(**p)
+        m.set_option("path", path)
+        got = m.compute(left, right)
+        assert np.array_equal(got, want), "path %d: %d pixels differ" % (path, (got != want).sum())
+    l2, r2 = synthetic.rectified_pair(seed=99, H=1080, W=1920, D=D, cn=3)
+    m = StereoSGBM_create(**p)
+    m.set_option("path", 2)
+    got = m.compute(np.stack([l2, left, l2[::-1].copy()]), np.stack([r2, right, r2[::-1].copy()]))
+    assert np.array_equal(got[1], want)
+
+
 def test_sgbm_full_size_rows_vs_oracle(oracle):
     """Full-width strip of the 1080p config against the oracle (the oracle finishes it in seconds)."""
     D = 128
