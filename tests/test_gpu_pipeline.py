@@ -173,11 +173,12 @@ def _oracle_get_depth(oracle, stereo, sgbm_params, img1, img2):
                 unrectify_depth=unrect, undistort_img1=undist)
 
 
-@pytest.mark.parametrize("W,H,max_depth", [(640, 480, None), (640, 480, 3.5), (320, 240, 3.0)])
+@pytest.mark.parametrize("W,H,max_depth", [(640, 480, None), (640, 480, 3.5), (320, 240, 3.0), (1920, 1080, 3.5)])
 def test_get_depth_end_to_end(oracle, W, H, max_depth):
-    """Config C5-like: full get_depth (rectify x2 + SGBM + disp_to_depth + unrectify + undistort)."""
+    """Config C5-like: full get_depth (rectify x2 + SGBM + disp_to_depth + unrectify + undistort); the last case is a
+    whole 1080p pair at D=128 (about ten seconds of oracle)."""
     stereo = ca.Stereo.load(synthetic.rig(W, H))
-    cfg = dict(max_size=max(W, H), minDisparity=0, numDisparities=64, blockSize=5, P1=8 * 3 * 25,
+    cfg = dict(max_size=max(W, H), minDisparity=0, numDisparities=128 if W > 1000 else 64, blockSize=5, P1=8 * 3 * 25,
                P2=32 * 3 * 25, disp12MaxDiff=1, uniquenessRatio=10, speckleWindowSize=100, speckleRange=2)
     stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=max_depth)
     img1, img2 = synthetic.scene_pair(9, W, H, 3)
@@ -192,7 +193,7 @@ def test_get_depth_end_to_end(oracle, W, H, max_depth):
         assert got[k].dtype == np.float64
         assert np.array_equal(got[k] == 0, ref[k] == 0), k
         assert np.abs(got[k] - ref[k]).max() <= DEPTH_TOL, k
-    assert (got["rectify_depth"] > 0).mean() > 0.05
+    assert (got["rectify_depth"] > 0).mean() > 0.03  # (sanity only: the synthetic scene is mostly beyond max_depth)
     # tensors in -> tensors out, same numbers
     gt = stereo.get_depth(torch.from_numpy(img1).cuda(), torch.from_numpy(img2).cuda())
     assert gt["unrectify_depth"].is_cuda
