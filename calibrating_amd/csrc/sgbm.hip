@@ -671,6 +671,7 @@ struct camd_sgbm {
     camd::CostRanges cr;  // row ranges of the cost volume: the image, or the 3WAY stripes (each a "virtual pair")
     int stripe_sz;        // 3WAY: rows a stripe owns
     int16_t* rawv;        // 3WAY: raw disparity per virtual pair [max_batch * cr.n][ga.H][W]
+    uint32_t* cost_ovf;   // per volume: the wrapping cost kernel saw a value too close to 32767 (two-stage saturating build)
     int way3_simd_lanes;  // 3WAY winner-take-all tie rule: 8 = cv2's SSE / NEON builds (default), 1 = scalar build
     camd_sgbm_params params;
     int max_batch;
@@ -996,6 +997,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         if (e == hipSuccess && way3) e = hipMalloc((void**)&h->rawv, nvol * align_up((size_t)vrows * width * 2, 256));
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->raw, (size_t)max_batch * raw_e * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->cost_ovf, nvol * 4);
     size_t sws = speckle_ws_bytes(width, height, max_batch);
     if (e == hipSuccess && g.speckleWindowSize > 0) e = hipMalloc(&h->speckle_ws, sws);
     h->band_ok = band_supported(g);
@@ -1038,7 +1040,7 @@ int camd_sgbm_destroy(camd_sgbm* h)
     if (h->ev_ok)
         for (int i = 0; i <= ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
     (void)hipFree(h->C); (void)hipFree(h->S);
-    (void)hipFree(h->raw); (void)hipFree(h->rawv); (void)hipFree(h->speckle_ws);
+    (void)hipFree(h->raw); (void)hipFree(h->rawv); (void)hipFree(h->speckle_ws); (void)hipFree(h->cost_ovf);
     (void)hipFree(h->E); (void)hipFree(h->flags); (void)hipFree(h->ticket); (void)hipFree(h->keys);
     (void)hipFree(h->d1); (void)hipFree(h->Smulti);
     if (h->err_host) (void)hipHostFree(h->err_host);
@@ -1182,33 +1184,48 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         const int nw = g.Dp / COST_DL < 4 ? 4 : (g.Dp / COST_DL < maxw ? g.Dp / COST_DL : maxw);
         const int ndblk = div_up(g.Dp, nw * COST_DL);                   // disparity blocks of <= 128
         const int nstrips = div_up(g.W1, 64 - (K - 1));
-        // row chunks: enough workgroups for ~32 rounds over the chip, but the saturating recurrence must start at row 0
-        int nchunks = 1;
-        if (!sat) {
-            nchunks = div_up(8192, (long long)nstrips * ndblk * vbatch);
-            const int maxc = h->ga.H / 32 > 1 ? h->ga.H / 32 : 1;
-            nchunks = nchunks < 1 ? 1 : (nchunks > maxc ? maxc : nchunks);
-        }
-        const int rb = div_up(h->ga.H, nchunks);  // rows per chunk, in the longest range
-        nchunks = div_up(h->ga.H, rb);
-        dim3 grid(nstrips, nchunks * ndblk, vbatch), block(64 * nw);
-        const size_t lds = cost_lds_bytes(g.cn, nw);
+        // row chunks: enough workgroups for ~32 rounds over the chip.  The saturating recurrence must start at row 0
+        // (one chunk: few workgroups, a long walk) -- but it only differs from the wrapping one on images that drive a
+        // window sum to within one horizontal sum of 32767, so where the true sums cannot wrap 16 bits the chunked
+        // wrapping kernel runs first and flags the volumes that need the sequential kernel (sgbm_cost.hpp)
+        const int tbound = K * g.cn * (2 * g.ftzero + 63);
+        const bool two_stage = sat && (long long)K * tbound + g.P2 <= 65535;
+        auto launch_cost = [&](bool sat_kernel, uint32_t* ovf, int thresh) {
+            int nchunks = 1;
+            if (!sat_kernel) {
+                nchunks = div_up(8192, (long long)nstrips * ndblk * vbatch);
+                const int maxc = h->ga.H / 32 > 1 ? h->ga.H / 32 : 1;
+                nchunks = nchunks < 1 ? 1 : (nchunks > maxc ? maxc : nchunks);
+            }
+            const int rb = div_up(h->ga.H, nchunks);  // rows per chunk, in the longest range
+            nchunks = div_up(h->ga.H, rb);
+            dim3 grid(nstrips, nchunks * ndblk, vbatch), block(64 * nw);
+            const size_t lds = cost_lds_bytes(g.cn, nw);
 #define CAMD_COST(CNN, KK, SS)                                                                                       \
     hipLaunchKernelGGL((k_cost<CNN, KK, SS>), grid, block, lds, st, left, right, pitch, image_stride, h->C, g, rb, \
-                       nchunks, h->vol_elems, h->cr)
-#define CAMD_COST_K(CNN)                                                                  \
-    switch (K) {                                                                          \
-        case 1: CAMD_COST(CNN, 1, false); break;                                          \
-        case 3: CAMD_COST(CNN, 3, false); break;                                          \
-        case 5: if (sat) CAMD_COST(CNN, 5, true); else CAMD_COST(CNN, 5, false); break;   \
-        case 7: if (sat) CAMD_COST(CNN, 7, true); else CAMD_COST(CNN, 7, false); break;   \
-        case 9: if (sat) CAMD_COST(CNN, 9, true); else CAMD_COST(CNN, 9, false); break;   \
-        default: if (sat) CAMD_COST(CNN, 11, true); else CAMD_COST(CNN, 11, false);       \
+                       nchunks, h->vol_elems, h->cr, ovf, thresh)
+#define CAMD_COST_K(CNN)                                                                         \
+    switch (K) {                                                                                 \
+        case 1: CAMD_COST(CNN, 1, false); break;                                                 \
+        case 3: CAMD_COST(CNN, 3, false); break;                                                 \
+        case 5: if (sat_kernel) CAMD_COST(CNN, 5, true); else CAMD_COST(CNN, 5, false); break;   \
+        case 7: if (sat_kernel) CAMD_COST(CNN, 7, true); else CAMD_COST(CNN, 7, false); break;   \
+        case 9: if (sat_kernel) CAMD_COST(CNN, 9, true); else CAMD_COST(CNN, 9, false); break;   \
+        default: if (sat_kernel) CAMD_COST(CNN, 11, true); else CAMD_COST(CNN, 11, false);       \
     }
-        // (K <= 3 cannot overflow: 9 * 3 * 317 + 16000 < 32768)
-        if (g.cn == 1) { CAMD_COST_K(1) } else { CAMD_COST_K(3) }
+            if (g.cn == 1) { CAMD_COST_K(1) } else { CAMD_COST_K(3) }
 #undef CAMD_COST_K
 #undef CAMD_COST
+        };
+        if (two_stage) {
+            CAMD_HIP(hipMemsetAsync(h->cost_ovf, 0, (size_t)vbatch * 4, st));
+            launch_cost(false, h->cost_ovf, 32767 - tbound);
+            CAMD_LAUNCH_CHECK();
+            launch_cost(true, h->cost_ovf, -1);
+        } else {
+            launch_cost(sat, nullptr, -1);
+        }
+        // (K <= 3 cannot overflow: 9 * 3 * 317 + 16000 < 32768)
         CAMD_LAUNCH_CHECK();
     }
     MARK(ST_HSUM);

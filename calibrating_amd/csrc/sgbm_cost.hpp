@@ -24,7 +24,11 @@
 // in the vertical recurrence, in OpenCV's operation order: column 0  C = (Cprev + hsumAdd) - hsumSub, columns
 // >= 1  C = (Cprev - hsumSub) + hsumAdd, first row  C = P2 + (SH2+1)*h(0) + h(1) + ...; the recurrence then
 // has to start at row 0 (one row chunk).  SAT = false wraps modulo 2^16 like the scalar build's (CostType)
-// casts.  The two agree whenever K*K*cn*(2*ftzero + 63) + P2 <= 32767.
+// casts.  The two agree whenever K*K*cn*(2*ftzero + 63) + P2 <= 32767 -- and, image by image,
+// whenever no value of the volume comes within one horizontal sum (K*cn*(2*ftzero + 63)) of 32767: then no
+// intermediate of the saturating recurrence can clip either.  The host uses that (sgbm.hip): the chunked wrapping
+// kernel runs first and reports per volume whether the bound held (ovf / ovf_thresh); the sequential saturating
+// kernel, a single row chunk and therefore few workgroups, re-does only the volumes where it did not.
 #pragma once
 
 namespace camd {
@@ -102,7 +106,8 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <int CN, int K, bool SAT>
 __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
-                                               Geom g, int rb, int nchunks, size_t vol_stride, CostRanges cr)
+                                               Geom g, int rb, int nchunks, size_t vol_stride, CostRanges cr,
+                                               uint32_t* __restrict__ ovf, int ovf_thresh)
 {
     constexpr int DL = COST_DL;
     constexpr int ES = CN == 1 ? 4 : 12;  // dwords per staged entry: (p, lo, hi) per channel, padded to 16 bytes
@@ -118,6 +123,11 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     const int vpair = blockIdx.z, pair = vpair / cr.n, ridx = vpair % cr.n;  // volume index, image index, range
     const int ybase = cr.start[ridx], nrows = cr.rows[ridx];
     if (chunk * rb >= nrows) return;  // (ranges shorter than the longest one: whole workgroup, before any barrier)
+    // Two-stage build of a saturating volume (sgbm.hip): the wrapping kernel (SAT = false, rows in parallel chunks)
+    // raises ovf[volume] when a value it writes exceeds ovf_thresh; this sequential kernel then only runs for the
+    // volumes whose flag is up
+    if (SAT && ovf && !ovf[vpair]) return;
+    uint32_t ovf_max = 0;
     const int W1 = g.W1, H = g.H;
     const int xo0 = blockIdx.x * XS, xs0 = xo0 - SW2;                 // first output column, column of lane 0
     const int cmin = max(xs0, 0), cmax = min(xs0 + 63, W1 - 1);       // clamped column range of the strip
@@ -332,6 +342,8 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
                     const int y = y0 + r - (K - 1);
                     uint4* o = reinterpret_cast<uint4*>(outp + (size_t)y * W1 * g.Dp);
                     *o = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                    if (!SAT && ovf_thresh >= 0)  // (uniform)
+                        ovf_max = pk_max_u16(pk_max_u16(ovf_max, pk_max_u16(acc[0], acc[1])), pk_max_u16(acc[2], acc[3]));
                 }
                 // entries of row r+1 from the rows fetched one step ago; then fetch for row r+2
                 stage_entries((r + 1) & 1);
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
             }
         }
     }
+    if (!SAT && ovf_thresh >= 0 && (int)max(ovf_max & 0xffffu, ovf_max >> 16) > ovf_thresh) atomicOr(ovf + vpair, 1u);
 }
 
 }  // namespace camd

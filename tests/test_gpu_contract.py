@@ -122,8 +122,8 @@ def test_get_depth_reads_image_files(tmp_path):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
 
 
-def _c_volume(matcher):
-    return matcher.debug_volume("C").cpu().numpy()
+def _c_volume(matcher, index=0):
+    return matcher.debug_volume("C", index).cpu().numpy()
 
 
 def _sawtooth_pair(H, W):
@@ -165,6 +165,27 @@ def test_u7_saturate_switch_matches_oracle(oracle, saturate, cost_path, cap):
             assert (want < 0).any(), "the case must actually wrap"
     finally:
         oracle.set_switches()
+
+
+def test_u7_two_stage_build_flags_only_the_saturating_pairs(oracle):
+    """The saturating volume is built in two stages (sgbm_cost.hpp): row chunks in parallel with wrapping arithmetic,
+    then the sequential saturating kernel for the volumes in which a value came close to 32767.  A batch that mixes
+    ordinary pairs with a saturating one, tall enough for several row chunks: every pair must equal the oracle, cost
+    volume and disparity."""
+    H, W, D = 100, 260, 96
+    saw = _sawtooth_pair(H, W)
+    tex = synthetic.rectified_pair(seed=3, H=H, W=W, D=D, cn=3)
+    tex2 = synthetic.rectified_pair(seed=4, H=H, W=W, D=D, cn=3)
+    p = dict(minDisparity=0, numDisparities=D, blockSize=11, P1=968, P2=3872, disp12MaxDiff=1, uniquenessRatio=5,
+             preFilterCap=31)
+    pairs = [tex, saw, tex2, saw]
+    m = ca.StereoSGBM_create(**p)
+    got = m.compute(np.stack([a for a, _ in pairs]), np.stack([b for _, b in pairs]))
+    vols = [oracle.sgbm_cost_volume(a, b, **p) for a, b in pairs]
+    assert vols[0].max() < 32767 - 11 * 3 * 125 and (vols[1] == 32767).any()  # one kind of each
+    for i, (a, b) in enumerate(pairs):
+        assert np.array_equal(got[i], oracle.sgbm_compute(a, b, **p)), i
+        assert np.array_equal(_c_volume(m, i), vols[i]), i
 
 
 def test_u7_modes_agree_without_overflow(oracle):
