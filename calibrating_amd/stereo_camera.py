@@ -337,8 +337,8 @@ class Stereo:
         Not in the reference (its ``get_depth`` takes one pair, stereo_camera.py:491-533); this is the
         throughput form of the same stages -- each kernel is launched once for the whole batch, which is
         what keeps small images (VGA) from being launch-bound.  Pair ``i`` of the result is bit-identical
-        to ``get_depth(imgs1[i], imgs2[i])``.  Requires the SGBM plugin with ``max_size`` >= the RECTIFIED
-        image size (the size the matcher sees, as in get_depth).
+        to ``get_depth(imgs1[i], imgs2[i])``.  Requires the SGBM plugin; a ``max_size`` below the rectified image
+        size downsizes the whole batch first, as the matcher does for one pair.
         """
         assert hasattr(self, "stereo_matching"), "Please stereo.set_stereo_matching(stereo_matching)"
         i1, was_np = self._to_dev(imgs1)
@@ -348,12 +348,18 @@ class Stereo:
         if not isinstance(self.stereo_matching, SemiGlobalBlockMatching):
             raise ValueError("get_depth_batch needs a SemiGlobalBlockMatching plugin")
         rectify_img1, rectify_img2 = self.rectify(i1, i2)
+        import torch
         sm = self._sgbm_full_res(rectify_img1.shape[1:3])
-        if sm is None:
-            raise ValueError("get_depth_batch needs max_size >= the rectified image size %s (got max_size=%s)"
-                             % (tuple(rectify_img1.shape[1:3]), self.stereo_matching.max_size))
         tb = self._tables(i1.device)
-        disparity, rectify_depth = self._fused_depth(sm, sm.stereo_sgbm.compute(rectify_img1, rectify_img2), tb)
+        if sm is not None:
+            disparity, rectify_depth = self._fused_depth(sm, sm.stereo_sgbm.compute(rectify_img1, rectify_img2), tb)
+        else:  # the downsizing matcher, stage by stage like get_depth's general branch
+            sm = self.stereo_matching
+            disparity = sm.call_batch(rectify_img1, rectify_img2)
+            if self.translation_rectify_img:
+                disparity += self.min_disparity
+            disparity = tb["mask"].to(torch.bool) * disparity
+            rectify_depth = self.disparity_to_depth(disparity)
         result = dict(rectify_img1=rectify_img1, rectify_depth=rectify_depth, disparity=disparity,
                       rectify_img2=rectify_img2)
         if return_unrectify_depth:

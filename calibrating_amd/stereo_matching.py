@@ -53,13 +53,29 @@ class SemiGlobalBlockMatching(MetaStereoMatching):
             mode=self.cfg.get("mode", MODE_SGBM),
         )
 
-    def compute_disp16(self, img1, img2):
+    def compute_disp16(self, img1, img2, batched=False):
         """Device-resident stage used by ``Stereo.get_depth``: int16 disparity*16 of the (possibly
-        downsized) pair plus the resize ratio; torch tensors in, torch tensor out."""
-        h, w = img1.shape[:2]
+        downsized) pair plus the width it was computed at; torch tensors in, torch tensor out.
+        ``batched``: (n, h, w, c) stacks of pairs, one launch per stage."""
+        lead = 1 if batched else 0
+        h, w = img1.shape[lead:lead + 2]
         resize_ratio = min(self.max_size / max(h, w), 1)
-        simg1, simg2 = _resize.resize(img1, resize_ratio), _resize.resize(img2, resize_ratio)
-        return self.stereo_sgbm.compute(simg1, simg2), simg1.shape[1]
+        simg1, simg2 = _resize.resize(img1, resize_ratio, batched), _resize.resize(img2, resize_ratio, batched)
+        return self.stereo_sgbm.compute(simg1, simg2), simg1.shape[lead + 1]
+
+    def _disparity_from_disp16(self, sdisp16, hw, sw, batched=False):
+        # stereo_matching.py:63-69: float32, clip at 0, below minDisparity -> 0, /16, back to the input size, x w/sw
+        import torch
+        sdisparity = sdisp16.to(torch.float32).clamp_(min=0)
+        sdisparity[sdisparity < self.stereo_sgbm.getMinDisparity() * 16] = 0
+        return _resize.resize(sdisparity / 16.0, hw, batched) * hw[1] / sw
+
+    def call_batch(self, imgs1, imgs2):
+        """``__call__`` for (n, h, w, 3) CUDA stacks of rectified pairs -> (n, h, w) float32 disparities; pair i equals
+        ``self(imgs1[i], imgs2[i])``.  Not in the reference (one pair per call); used by ``Stereo.get_depth_batch``."""
+        hw = tuple(imgs1.shape[1:3])
+        sdisp16, sw = self.compute_disp16(imgs1, imgs2, batched=True)
+        return self._disparity_from_disp16(sdisp16, hw, sw, batched=True)
 
     def __call__(self, img1, img2):
         import torch
@@ -67,9 +83,6 @@ class SemiGlobalBlockMatching(MetaStereoMatching):
         if is_np:
             img1, img2 = torch.from_numpy(np.ascontiguousarray(img1)).cuda(), \
                 torch.from_numpy(np.ascontiguousarray(img2)).cuda()
-        h, w = img1.shape[:2]
         sdisp16, sw = self.compute_disp16(img1, img2)
-        sdisparity = sdisp16.to(torch.float32).clamp_(min=0)
-        sdisparity[sdisparity < self.stereo_sgbm.getMinDisparity() * 16] = 0
-        disparity = _resize.resize(sdisparity / 16.0, (h, w)) * w / sw
+        disparity = self._disparity_from_disp16(sdisp16, tuple(img1.shape[:2]), sw)
         return hostio.to_host(disparity) if is_np else disparity

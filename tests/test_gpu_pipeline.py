@@ -222,13 +222,16 @@ def test_get_depth_requires_matcher():
         ca.MetaStereoMatching()(None, None)
 
 
-def test_get_depth_batch_matches_per_pair():
-    """The batched throughput form returns, pair by pair, exactly what get_depth returns."""
+@pytest.mark.parametrize("max_size,max_depth", [(320, 3.5), (200, 3.5), (250, None)])
+def test_get_depth_batch_matches_per_pair(max_size, max_depth):
+    """The batched throughput form returns, pair by pair, exactly what get_depth returns -- at the matcher's full
+    resolution (fused depth kernel) and through its max_size downsizing (the reference's default: resize, match,
+    resize back), with and without the min_disparity translation."""
     W, H = 320, 240
     stereo = ca.Stereo.load(synthetic.rig(W, H))
-    cfg = dict(max_size=W, minDisparity=0, numDisparities=64, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+    cfg = dict(max_size=max_size, minDisparity=0, numDisparities=64, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
                uniquenessRatio=10, speckleWindowSize=50, speckleRange=2)
-    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=3.5)
+    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=max_depth)
     pairs = [synthetic.scene_pair(s, W, H, 3) for s in (1, 2, 3, 4, 5)]
     I1 = np.stack([p[0] for p in pairs]); I2 = np.stack([p[1] for p in pairs])
     got = stereo.get_depth_batch(I1, I2)

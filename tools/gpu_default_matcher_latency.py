@@ -28,4 +28,15 @@ torch.cuda.synchronize(); res["matcher_call_ms"] = (time.perf_counter() - t0) / 
 m = sm.stereo_sgbm
 m.set_profiling(True); sm(r1, r2); torch.cuda.synchronize()
 res["sgbm_stages_ms"] = {k: round(v, 3) for k, v in m.stage_times_ms().items()}
+# the same configuration through the batched form: 64 pairs of 1080p per call
+nb = 64
+pairs = [synthetic.scene_pair(100 + i, W, H, 3) for i in range(4)]
+B1 = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(nb)])).cuda()
+B2 = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(nb)])).cuda()
+for _ in range(2): stereo.get_depth_batch(B1, B2)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): stereo.get_depth_batch(B1, B2)
+torch.cuda.synchronize(); res["get_depth_batch64_pairs_per_s"] = nb * 3 / (time.perf_counter() - t0)
 print(json.dumps(res, indent=1))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/default_matcher.json", "w"), indent=1)
