@@ -1293,7 +1293,13 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         if (batch * pair_work(g) <= auto_concurrent_limit(g) || !h->band_ok) path = CAMD_PATH_CONCURRENT;
         else path = CAMD_PATH_BAND;
     }
-    if (way3 && path != CAMD_PATH_SCAN) path = CAMD_PATH_BAND;  // (no per-direction volumes for the stripes)
+    if (way3) {
+        // no per-direction volumes for the stripes: band passes, or three line scans + k_wta.  The wavefront of a
+        // band pass fills slowly, so for little work the scans win (ms per pair, scans / band, 1080p D=128: 2.1 / 4.2
+        // for one pair, 1.65 / 1.38 for four; VGA D=64: 0.36 / 1.09 for one, 0.125 / 0.10 for sixteen)
+        if (h->path == CAMD_PATH_AUTO) path = batch * pair_work(g) < 2.5 ? CAMD_PATH_SCAN : CAMD_PATH_BAND;
+        else if (path != CAMD_PATH_SCAN) path = CAMD_PATH_BAND;
+    }
     if (path == CAMD_PATH_BAND && !h->band_ok) path = CAMD_PATH_SCAN;
     // the per-direction volumes were sized in create / set_option: a larger batch takes the next best path
     if (path == CAMD_PATH_CONCURRENT && batch > mcap) path = h->band_ok ? CAMD_PATH_BAND : CAMD_PATH_SCAN;

@@ -82,7 +82,8 @@ int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* st
  *   CAMD_PATH_SCAN            one line-scan launch per direction, sequential (generic fallback)
  *   CAMD_PATH_BAND            fused band-wavefront passes (throughput; D in (32, 256])
  *   CAMD_PATH_CONCURRENT      all directions at once into per-direction volumes (latency; <= 8 pairs per call)
- * MODE_SGBM_3WAY has no per-direction volumes: every value but CAMD_PATH_SCAN runs its stripes through the band passes
+ * MODE_SGBM_3WAY has no per-direction volumes: AUTO takes the line scans for little work per call (under ~2.5 pairs of
+ * 1080p/D=128-sized work) and the band passes above; CAMD_PATH_BAND / CAMD_PATH_CONCURRENT force the band passes
  * (where D allows; the winners are decided inside the last pass for D % 8 == 0, by a separate kernel otherwise).
  * CAMD_OPT_KEEP_S 1 = the band path also stores the final S volume (for camd_sgbm_debug_copy(which = 1)). */
 enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1, CAMD_OPT_COST = 2, CAMD_OPT_SATURATE = 3, CAMD_OPT_3WAY_SIMD_LANES = 4 };

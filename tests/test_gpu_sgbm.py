@@ -213,7 +213,7 @@ def test_sgbm_full_size_rows_vs_oracle(oracle):
     (68, 160, 16, 1, 0, 0, dict(uniquenessRatio=0)),   # blockSize 0 -> radius 1 in this mode; uniqueness test off
     (97, 330, 200, 1, 5, 0, {}),                      # D > 128: two 8-groups per lane
 ])
-@pytest.mark.parametrize("path", [0, 1])  # 0: two band passes where the shape allows, 1: three line scans
+@pytest.mark.parametrize("path", [2, 1, 0])  # 2: two band passes where the shape allows, 1: three line scans, 0: AUTO
 def test_sgbm_3way_vs_oracle(oracle, H, W, D, cn, bs, minD, extra, path):
     left, right = synthetic.rectified_pair(seed=21, H=H, W=W, D=max(D, 8), cn=cn)
     b = bs if bs > 0 else 3
@@ -246,11 +246,12 @@ def test_sgbm_3way_tie_rule(oracle, lanes):
             flat = np.full((H, W), 15, np.uint8)
             p = dict(minDisparity=0, numDisparities=D, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, uniquenessRatio=0,
                      mode=ca.MODE_SGBM_3WAY)
-            m = ca.StereoSGBM_create(**p)
-            m.set_option("way3_simd_lanes", lanes)
-            got = m.compute(flat, flat)
             want = oracle.sgbm_compute(flat, flat, **p)
-            assert np.array_equal(got, want), (lanes, D, (got != want).sum())
+            for path in (2, 1):  # band passes (tie rule inside the last pass where D % 8 == 0) and line scans + k_wta
+                m = ca.StereoSGBM_create(**p)
+                m.set_option("way3_simd_lanes", lanes).set_option("path", path)
+                got = m.compute(flat, flat)
+                assert np.array_equal(got, want), (lanes, D, path, (got != want).sum())
             raw = oracle.sgbm_compute(flat, flat, raw=True, **p)
             assert raw[H // 2, W - 1] == (winner8 * 16 if lanes == 8 else 0), (lanes, D, raw[H // 2, W - 1])
     finally:
@@ -271,7 +272,7 @@ def test_sgbm_3way_ties_next_to_texture(oracle, D):
     p = dict(minDisparity=0, numDisparities=D, blockSize=3, P1=20, P2=80, disp12MaxDiff=1, uniquenessRatio=0,
              mode=ca.MODE_SGBM_3WAY)
     want = oracle.sgbm_compute(left, right, **p)
-    for path in (0, 1):
+    for path in (2, 1):
         m = ca.StereoSGBM_create(**p)
         m.set_option("path", path)
         got = m.compute(left, right)

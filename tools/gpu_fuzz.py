@@ -19,6 +19,7 @@ for case in range(n):
     bs = int(rng.choice([0, 1, 3, 5, 7, 9, 11]))
     minD = int(rng.integers(-9, 10))
     mode = int(rng.choice([0, 1, 2, 3]))
+    force_band = bool(rng.integers(0, 2))  # (AUTO sends small 3WAY calls down the scan path)
     b = max(bs, 1)
     W = D + abs(minD) + int(rng.integers(b // 2 + 2, 140))
     H = int(rng.integers(3, 90)) if mode != 2 else int(rng.integers(40, 110))
@@ -48,6 +49,8 @@ for case in range(n):
         for cost in ((1, 2) if mode != 2 and bs <= 11 else (0,)):
             m = ca.StereoSGBM_create(**p)
             m.set_option("cost", cost)
+            if mode == 2 and force_band:
+                m.set_option("path", 2)
             nb = int(rng.choice([1, 1, 3]))
             got = m.compute(np.stack([left] * nb), np.stack([right] * nb)) if nb > 1 else m.compute(left, right)[None]
             for i in range(nb):
