@@ -33,6 +33,9 @@ rows.sort()
 print("slowest (cell-paths per us):")
 for r in rows[:25]:
     print("%8.0f  %dx%d D=%d bs=%d cn=%d mode=%d batch=%d  %.3f ms" % r)
+print("slowest at 16 pairs per call:")
+for r in [r for r in rows if r[7] == 16][:25]:
+    print("%8.0f  %dx%d D=%d bs=%d cn=%d mode=%d batch=%d  %.3f ms" % r)
 print("fastest:")
 for r in rows[-5:]:
     print("%8.0f  %dx%d D=%d bs=%d cn=%d mode=%d batch=%d  %.3f ms" % r)
