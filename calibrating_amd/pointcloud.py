@@ -9,7 +9,6 @@ import ctypes
 import numpy as np
 
 from . import _native, hostio
-from .geometry import inv3
 
 
 def _to_dev(a, dtype):
