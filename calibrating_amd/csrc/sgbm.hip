@@ -944,6 +944,7 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     size_t vol = align_up((size_t)vrows * w1 * g.Dp * 2, 256);
     size_t raw = align_up((size_t)height * width * 2, 256);
     size_t total = (size_t)max_batch * (2 * cr.n * vol + raw);
+    total += (size_t)max_batch * cr.n * 4;  // per-volume flags of the two-stage saturating cost build
     if (way3) total += (size_t)max_batch * cr.n * align_up((size_t)vrows * width * 2, 256);
     if (g.speckleWindowSize > 0) total += speckle_ws_bytes(width, height, max_batch);
     const bool band_ok = band_supported(g);
