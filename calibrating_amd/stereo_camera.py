@@ -181,7 +181,11 @@ class Stereo:
         return float(np.sqrt(np.sum(np.square(self.t))))
 
     def depth_to_disparity(self, depth):
-        return 1.0 * self.baseline * self.K[0, 0] / depth
+        bf = 1.0 * self.baseline * self.K[0, 0]
+        if isinstance(depth, np.ndarray) or np.isscalar(depth):
+            return bf / depth
+        import torch  # float64 like NumPy's float64-scalar / array, and an IEEE division (see disparity_to_depth)
+        return torch.full((), float(bf), dtype=torch.float64, device=depth.device) / depth.to(torch.float64)
 
     def disparity_to_depth(self, disparity):
         """NumPy or torch ``disparity`` -> depth, same dtype rules and edge cases as :408-413: inf (d = 0)
@@ -192,7 +196,8 @@ class Stereo:
                 depth = bf / disparity
         else:
             import torch
-            depth = float(bf) / disparity.to(torch.float64)
+            # (a tensor numerator: `number / tensor` would be computed as reciprocal(tensor) * number, two roundings)
+            depth = torch.full((), float(bf), dtype=torch.float64, device=disparity.device) / disparity.to(torch.float64)
         depth[depth > self.get_max_depth()] = 0
         depth[depth < 0] = 0
         return depth

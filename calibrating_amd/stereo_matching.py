@@ -68,7 +68,10 @@ class SemiGlobalBlockMatching(MetaStereoMatching):
         import torch
         sdisparity = sdisp16.to(torch.float32).clamp_(min=0)
         sdisparity[sdisparity < self.stereo_sgbm.getMinDisparity() * 16] = 0
-        return _resize.resize(sdisparity / 16.0, hw, batched) * hw[1] / sw
+        up = _resize.resize(sdisparity / 16.0, hw, batched) * hw[1]  # (/16 is exact in any form)
+        # NumPy's `x * w / sw` divides; torch turns a division by a Python number into a multiplication by its
+        # reciprocal (one ulp off now and then), a tensor divisor gets the IEEE division
+        return up / torch.full((), float(sw), dtype=torch.float32, device=up.device)
 
     def call_batch(self, imgs1, imgs2):
         """``__call__`` for (n, h, w, 3) CUDA stacks of rectified pairs -> (n, h, w) float32 disparities; pair i equals

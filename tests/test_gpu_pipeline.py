@@ -279,3 +279,16 @@ def test_stereo_device_tables_match_host_properties():
     assert np.array_equal(tb["map2x"].cpu().numpy(), stereo.undistort_rectify_map2[0])
     assert np.array_equal(tb["map2y"].cpu().numpy(), stereo.undistort_rectify_map2[1])
     assert np.array_equal(tb["mask"].cpu().numpy().astype(bool), stereo.rectify_valid_mask1)
+
+
+def test_disparity_to_depth_tensor_branch_divides_like_numpy():
+    """Stereo.disparity_to_depth on a CUDA tensor (the branch behind foreign plugins and the downsizing matcher) gives
+    bit for bit what the reference's NumPy line gives: one IEEE division, zeros for inf / beyond max_depth / negatives."""
+    stereo = ca.Stereo.load(synthetic.rig(320, 240))
+    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(max_size=320)), max_depth=3.5)
+    rng = np.random.default_rng(8)
+    disp = rng.uniform(-3, 120, (240, 320)).astype(np.float32)
+    disp[::9, ::7] = 0
+    want = stereo.disparity_to_depth(disp.copy())
+    got = stereo.disparity_to_depth(torch.from_numpy(disp).cuda()).cpu().numpy()
+    assert got.dtype == want.dtype == np.float64 and np.array_equal(got, want)

@@ -82,7 +82,7 @@ def test_default_plugin_config_with_max_size(oracle):
     sd[sd < 2 * 16] = 0
     want = oracle.resize_linear(sd / np.float32(16.0), (H, W)) * W / hw[1]
     assert got.shape == (H, W) and got.dtype == np.float32
-    assert np.abs(got - want).max() <= 1e-4
+    assert np.array_equal(got, want)  # float32 op for op like NumPy: * w, then a true division by sw
     # and through Stereo.get_depth (non-fused branch of get_depth)
     stereo = ca.Stereo.load(synthetic.rig(W, H))
     stereo.set_stereo_matching(m, max_depth=3.5)
