@@ -14,7 +14,7 @@ from test_gpu_pipeline import _oracle_get_depth, DEPTH_TOL
 oracle.build()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
-bad = checked_full = checked_batch = 0
+bad = checked_full = checked_batch = checked_down = 0
 for case in range(n):
     W, H = int(rng.choice([160, 200, 256, 320])), int(rng.choice([96, 120, 150, 200]))
     f = W * rng.uniform(0.6, 1.1)
@@ -53,6 +53,26 @@ for case in range(n):
             if not np.array_equal(got[k], ref[k]): problems.append(k)
         for k in ("rectify_depth", "unrectify_depth"):
             if not np.array_equal(got[k] == 0, ref[k] == 0) or np.abs(got[k] - ref[k]).max() > DEPTH_TOL: problems.append(k)
+    else:  # the downsizing matcher (stereo_matching.py:60-70) composed from oracle stages, then stereo_camera.py:510-513
+        checked_down += 1
+        shift = stereo.min_disparity if stereo.translation_rectify_img else 0
+        r1 = oracle.remap_u8(img1, *stereo.undistort_rectify_map1, oracle.INTER_LANCZOS4)
+        r2 = oracle.remap_u8(img2, *stereo.undistort_rectify_map2, oracle.INTER_LANCZOS4)
+        if shift > 0:
+            r2[:, shift:] = r2[:, :-shift].copy()
+            r2[:, :shift] = 0
+        ratio = min(cfg["max_size"] / max(Ht, Wt), 1)
+        hw = (int(round(Ht * ratio)), int(round(Wt * ratio)))
+        sp = {k: v for k, v in cfg.items() if k != "max_size"}
+        sd = oracle.sgbm_compute(oracle.resize_linear(r1, hw), oracle.resize_linear(r2, hw), **sp).astype(np.float32).clip(0)
+        sd[sd < cfg["minDisparity"] * 16] = 0
+        disp = oracle.resize_linear(sd / np.float32(16.0), (Ht, Wt)) * Wt / hw[1]
+        if stereo.translation_rectify_img:
+            disp += stereo.min_disparity
+        disp = stereo.rectify_valid_mask1 * disp
+        depth = stereo.disparity_to_depth(disp)
+        if not np.array_equal(got["disparity"], disp): problems.append("down:disparity")
+        if not np.array_equal(got["rectify_depth"], depth): problems.append("down:rectify_depth")
     # batched form == per-call form, always (covers the downsizing branch too)
     i1b, i2b = synthetic.scene_pair(case + 1000, W, H, 3)
     checked_batch += 1
@@ -62,4 +82,4 @@ for case in range(n):
     if problems:
         bad += 1
         print("MISMATCH case", case, dict(W=W, H=H, target=(Wt, Ht), cfg=cfg, max_depth=max_depth), problems, flush=True)
-print("cases", n, "against the oracle", checked_full, "batch vs call", checked_batch, "mismatches", bad)
+print("cases", n, "against the oracle", checked_full, "downsizing branch against the oracle", checked_down, "batch vs call", checked_batch, "mismatches", bad)
