@@ -192,7 +192,8 @@ def test_get_depth_end_to_end(oracle, W, H, max_depth):
     for k in ("rectify_depth", "unrectify_depth"):
         assert got[k].dtype == np.float64
         assert np.array_equal(got[k] == 0, ref[k] == 0), k
-        assert np.abs(got[k] - ref[k]).max() <= DEPTH_TOL, k
+        assert np.abs(got[k] - ref[k]).max() <= DEPTH_TOL, k  # the stated bar (north_star: 1e-4 m) ...
+        assert np.array_equal(got[k], ref[k]), k              # ... and what is actually reached: the same float64 bits
     assert (got["rectify_depth"] > 0).mean() > 0.03  # (sanity only: the synthetic scene is mostly beyond max_depth)
     # tensors in -> tensors out, same numbers
     gt = stereo.get_depth(torch.from_numpy(img1).cuda(), torch.from_numpy(img2).cuda())
