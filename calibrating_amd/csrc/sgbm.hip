@@ -474,11 +474,22 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t KEY_INIT = 0x7fff0000u;
 
-template <int LANES, int NV>
+// EXACT (sgbm_exact.hpp): Sv points at nvol per-direction volumes of int L values (before narrowing); they are added
+// up in OpenCV's grouping and with each mode's own narrowing -- combine 0: saturate(L0 + L1 + L2 + L3) of the int
+// values, then saturate(that + the rest) (computeDisparitySGBM); 1: one saturating add per volume, in order, of
+// (CostType)L (computeDisparitySGBM_HH4); 2: the same of saturate(L) (the 3-way loop) -- and every total is carried
+// as S + 32768 in an unsigned half, so that all comparisons below order the same way; `bias` turns them back into
+// values where the arithmetic needs them.
+template <int LANES, int NV, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, int16_t* __restrict__ disp,
                                              size_t disp_pitch_e, size_t disp_stride_e, Geom g,
-                                             size_t vol_stride, int nvol, size_t dir_stride, int tie_lanes)
+                                             size_t vol_stride, int nvol, size_t dir_stride, int tie_lanes,
+                                             int combine = 0, const uint32_t* __restrict__ neg = nullptr, int vp = 0)
 {
+    if (EXACT && !neg[vp]) return;
+    constexpr int bias = EXACT ? 32768 : 0;
+    constexpr uint32_t key_init = EXACT ? 0xffff0000u : KEY_INIT;
+    constexpr int max_cost_b = MAX_COST + bias;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);          // [W]
     int16_t* d1row = reinterpret_cast<int16_t*>(keys + g.W);     // [W]
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
     const int INVALID_SCALED = (g.minD - 1) * 16;
 
     for (int x = threadIdx.x; x < g.W; x += 256) {
-        keys[x] = KEY_INIT;
+        keys[x] = key_init;
         d1row[x] = (int16_t)INVALID_SCALED;
     }
     __syncthreads();
@@ -498,21 +509,57 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
     const int dbase = li * 8 * NV;
     for (int x = grp; x < g.W1; x += GROUPS) {
         uint32_t s[NR];
-        const uint4* p = reinterpret_cast<const uint4*>(Srow + (size_t)x * g.Dp);
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            uint4 q = p[v];
-            s[4 * v] = q.x; s[4 * v + 1] = q.y; s[4 * v + 2] = q.z; s[4 * v + 3] = q.w;
-        }
-        // concurrent-direction path: S = saturating sum of the per-direction volumes
-        for (int dv = 1; dv < nvol; dv++) {
-            const uint4* pv = reinterpret_cast<const uint4*>(Srow + (size_t)dv * dir_stride + (size_t)x * g.Dp);
+        if (!EXACT) {
+            const uint4* p = reinterpret_cast<const uint4*>(Srow + (size_t)x * g.Dp);
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                uint4 q = pv[v];
-                s[4 * v] = pk_addsat_i16(s[4 * v], q.x); s[4 * v + 1] = pk_addsat_i16(s[4 * v + 1], q.y);
-                s[4 * v + 2] = pk_addsat_i16(s[4 * v + 2], q.z); s[4 * v + 3] = pk_addsat_i16(s[4 * v + 3], q.w);
+                uint4 q = p[v];
+                s[4 * v] = q.x; s[4 * v + 1] = q.y; s[4 * v + 2] = q.z; s[4 * v + 3] = q.w;
             }
+            // concurrent-direction path: S = saturating sum of the per-direction volumes
+            for (int dv = 1; dv < nvol; dv++) {
+                const uint4* pv = reinterpret_cast<const uint4*>(Srow + (size_t)dv * dir_stride + (size_t)x * g.Dp);
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    uint4 q = pv[v];
+                    s[4 * v] = pk_addsat_i16(s[4 * v], q.x); s[4 * v + 1] = pk_addsat_i16(s[4 * v + 1], q.y);
+                    s[4 * v + 2] = pk_addsat_i16(s[4 * v + 2], q.z); s[4 * v + 3] = pk_addsat_i16(s[4 * v + 3], q.w);
+                }
+            }
+        } else {
+            // (dir_stride and the row offsets count int elements here)
+            const int32_t* Lrow = reinterpret_cast<const int32_t*>(Sv) + ((size_t)y * g.W1 + x) * g.Dp + (size_t)li * (8 * NV);
+            int tot[2 * NR], part[2 * NR];
+#pragma unroll
+            for (int e = 0; e < 2 * NR; e++) tot[e] = part[e] = 0;
+            for (int dv = 0; dv <= nvol; dv++) {
+                // close the running group before volume dv joins: after every volume in the sequential modes, at the
+                // group boundary (after the first four volumes) and at the end in combine 0
+                if (dv > 0 && (combine != 0 || dv == 4 || dv == nvol)) {
+#pragma unroll
+                    for (int e = 0; e < 2 * NR; e++) {
+                        const int t = tot[e] + part[e];
+                        tot[e] = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+                        part[e] = 0;
+                    }
+                }
+                if (dv == nvol) break;
+                const int4* pv = reinterpret_cast<const int4*>(Lrow + (size_t)dv * dir_stride);
+#pragma unroll
+                for (int v = 0; v < 2 * NV; v++) {
+                    const int4 q = pv[v];
+                    const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int L = w[k];
+                        part[4 * v + k] += combine == 0 ? L : (combine == 1 ? (int)(int16_t)L
+                                                                             : (L < -32768 ? -32768 : (L > 32767 ? 32767 : L)));
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NR; k++)
+                s[k] = (uint32_t)(tot[2 * k] + bias) | ((uint32_t)(tot[2 * k + 1] + bias) << 16);
         }
         // (S << 16 | d) minimum: smallest S, then smallest d
         uint32_t key = 0xffffffffu;
@@ -560,28 +607,31 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
         }
         // uniqueness + the neighbours of the winner
         uint32_t flags = 0, sm = 0, spv = 0;
-        const int thr = minS * 100, mul = 100 - g.uniq;
+        const int thr = (minS - bias) * 100, mul = 100 - g.uniq;
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             int d0 = dbase + 2 * k;
-            int lo = (int)(s[k] & 0xffffu), hi = (int)(s[k] >> 16);
+            int lo = (int)(s[k] & 0xffffu) - bias, hi = (int)(s[k] >> 16) - bias;
             if (d0 < g.D) {
                 if (lo * mul < thr && abs(best - d0) > 1) flags = 1;
-                if (d0 == best - 1) sm = (uint32_t)lo;
-                if (d0 == best + 1) spv = (uint32_t)lo;
+                if (d0 == best - 1) sm = s[k] & 0xffffu;
+                if (d0 == best + 1) spv = s[k] & 0xffffu;
             }
             if (d0 + 1 < g.D) {
                 if (hi * mul < thr && abs(best - d0 - 1) > 1) flags = 1;
-                if (d0 + 1 == best - 1) sm = (uint32_t)hi;
-                if (d0 + 1 == best + 1) spv = (uint32_t)hi;
+                if (d0 + 1 == best - 1) sm = s[k] >> 16;
+                if (d0 + 1 == best + 1) spv = s[k] >> 16;
             }
         }
-        uint32_t packed = group_or_u32<LANES>((flags << 31) | (sm << 15) | spv);  // S values < 2^15
-        if (li == 0 && minS < MAX_COST && !(packed >> 31)) {
-            int Sm = (int)((packed >> 15) & 0x7fffu), Sp = (int)(packed & 0x7fffu);
+        // the two neighbours as 16-bit fields (each set by at most one lane; a field left at zero is never used)
+        const uint32_t packed = group_or_u32<LANES>((sm << 16) | spv);
+        flags = group_or_u32<LANES>(flags);
+        if (li == 0 && minS < max_cost_b && !flags) {
+            const int Sm = (int)(packed >> 16) - bias, Sp = (int)(packed & 0xffffu) - bias;
             int d = best;
             int x2 = x + g.minX1 - d - g.minD;
             atomicMin(&keys[x2], ((uint32_t)minS << 16) | (uint32_t)(0xffff - d));
+            minS -= bias;
             if (0 < d && d < g.D - 1) {
                 int denom2 = max(Sm + Sp - 2 * minS, 1);
                 d = d * 16 + ((Sm - Sp) * 16 + denom2) / (denom2 * 2);  // C division truncates
@@ -603,14 +653,14 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
             if (0 <= _x && _x < g.W) {
                 uint32_t k = keys[_x];
                 // untouched entries hold INVALID_DISP_SCALED and are compared unscaled (OpenCV quirk)
-                int v = k == KEY_INIT ? INVALID_SCALED : (int)(0xffffu - (k & 0xffffu)) + g.minD;
+                int v = k == key_init ? INVALID_SCALED : (int)(0xffffu - (k & 0xffffu)) + g.minD;
                 bad = v >= g.minD && abs(v - _d) > g.d12;
             } else
                 bad = false;
             if (bad) {
                 if (0 <= x_ && x_ < g.W) {
                     uint32_t k = keys[x_];
-                    int v = k == KEY_INIT ? INVALID_SCALED : (int)(0xffffu - (k & 0xffffu)) + g.minD;
+                    int v = k == key_init ? INVALID_SCALED : (int)(0xffffu - (k & 0xffffu)) + g.minD;
                     bad = v >= g.minD && abs(v - d_) > g.d12;
                 } else
                     bad = false;
@@ -630,6 +680,7 @@ __global__ void k_fill_s16(int16_t* p, size_t pitch_e, size_t stride_e, int W, i
 }  // namespace camd
 #include "sgbm_band.hpp"
 #include "sgbm_cost.hpp"
+#include "sgbm_exact.hpp"
 namespace camd {
 
 // MODE_SGBM_3WAY: rows of the final raw disparity come from the stripe that owns them
@@ -672,6 +723,10 @@ struct camd_sgbm {
     int stripe_sz;        // 3WAY: rows a stripe owns
     int16_t* rawv;        // 3WAY: raw disparity per virtual pair [max_batch * cr.n][ga.H][W]
     uint32_t* cost_ovf;   // per volume: the wrapping cost kernel saw a value too close to 32767 (two-stage saturating build)
+    uint32_t* cost_neg;   // per volume: C holds a value below P2 -> outside the packed-u16 regime (sgbm_exact.hpp)
+    bool may_overflow;    // the parameters allow an int16 overflow of the box sums at all
+    int exact_cap;        // 1: flagged volumes take the exact path (Lx allocated, CAMD_OPT_EXACT on); 0: they are refused
+    int32_t* Lx;          // exact path: npaths per-direction volumes of int L values for ONE flagged volume
     int way3_simd_lanes;  // 3WAY winner-take-all tie rule: 8 = cv2's SSE / NEON builds (default), 1 = scalar build
     camd_sgbm_params params;
     int max_batch;
@@ -791,6 +846,13 @@ static int cost_ranges(const Geom& g, int block_size_raw, CostRanges* cr, int* s
         if (cr->rows[s] > *max_rows) *max_rows = cr->rows[s];
     }
     return CAMD_OK;
+}
+
+// U7: an int16 overflow of the box sums is possible at all only beyond this bound
+static bool params_may_overflow(const Geom& g)
+{
+    const long long K = 2 * g.SW2 + 1;
+    return K * K * g.cn * (2 * g.ftzero + 63) + g.P2 > 32767;
 }
 
 // work of one pair in units of one 1080p / D=128 volume: the AUTO path rule and its workspace follow it
@@ -925,6 +987,77 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     return CAMD_OK;
 }
 
+// A flagged volume for which no exact workspace could be allocated: never hand back a silently different result --
+// its disparities are written as invalid and the handle reports an error (err = 2).
+__global__ __launch_bounds__(256) void k_poison_flagged(int16_t* __restrict__ raw, size_t stride_e, size_t n,
+                                                        const uint32_t* __restrict__ neg, uint32_t* __restrict__ err,
+                                                        int invalid)
+{
+    const int vp = blockIdx.y;
+    if (!neg[vp]) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        raw[(size_t)vp * stride_e + i] = (int16_t)invalid;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, 2u);
+}
+
+// the aggregation + winner-take-all of ONE (virtual) pair in int arithmetic (sgbm_exact.hpp); both kernels return at
+// once unless the volume is flagged.  dst: the raw disparity image of that (virtual) pair.
+static int launch_exact(const camd_sgbm* h, int vp, int16_t* dst, hipStream_t st)
+{
+    const Geom& g = h->ga;
+    // directions in the order OpenCV adds them up (it matters once sums saturate with negative terms in play)
+    static const int d_sgbm[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1}};
+    static const int d_hh4[4][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}};   // v, ^, ->, <-  (oracle/sgbm_ref.c:532-607)
+    static const int d_3way[3][2] = {{-1, 0}, {1, 0}, {0, 1}};           // (right + left) + top  (:789)
+    const int (*dirs)[2] = g.mode == CAMD_MODE_HH4 ? d_hh4 : (g.mode == CAMD_MODE_SGBM_3WAY ? d_3way : d_sgbm);
+    const int nd = g.npaths;
+    ScanDirs sd;
+    int maxlines = 0;
+    for (int i = 0; i < 8; i++) {
+        const int k = i < nd ? i : 0;
+        sd.dx[i] = dirs[k][0];
+        sd.dy[i] = dirs[k][1];
+        sd.nlines[i] = sd.dy[i] == 0 ? g.H : (sd.dx[i] == 0 ? g.W1 : g.W1 + g.H - 1);
+        if (i < nd && sd.nlines[i] > maxlines) maxlines = sd.nlines[i];
+    }
+    sd.dir_stride = h->vol_elems;  // (int elements)
+    const int16_t* C = reinterpret_cast<const int16_t*>(h->C) + (size_t)vp * h->vol_elems;
+    int32_t* L = h->Lx;
+    const bool way3 = g.mode == CAMD_MODE_SGBM_3WAY;
+    dim3 grid(div_up((long long)maxlines * g.lanes, 256), 1, nd);
+#define CAMD_XSCAN(LN, NVV)                                                                                        \
+    do {                                                                                                           \
+        if (way3) hipLaunchKernelGGL((k_scan_exact<LN, NVV, true>), grid, dim3(256), 0, st, C, L, g, sd, h->cost_neg, vp, 0); \
+        else hipLaunchKernelGGL((k_scan_exact<LN, NVV, false>), grid, dim3(256), 0, st, C, L, g, sd, h->cost_neg, vp,         \
+                                g.mode == CAMD_MODE_HH4 ? 1 : 0);                                                             \
+    } while (0)
+    if (g.lanes == 2) CAMD_XSCAN(2, 1);
+    else if (g.lanes == 4) CAMD_XSCAN(4, 1);
+    else if (g.lanes == 8) CAMD_XSCAN(8, 1);
+    else if (g.nv == 1) CAMD_XSCAN(16, 1);
+    else if (g.nv == 2) CAMD_XSCAN(16, 2);
+    else if (g.nv == 3) CAMD_XSCAN(16, 3);
+    else CAMD_XSCAN(16, 4);
+#undef CAMD_XSCAN
+    CAMD_LAUNCH_CHECK();
+    const int tie_lanes = way3 ? h->way3_simd_lanes : 0;
+    const int combine = g.mode == CAMD_MODE_HH4 ? 1 : (way3 ? 2 : 0);
+    size_t lds = align_up((size_t)g.W * 6, 16);
+#define CAMD_XWTA(LN, NVV)                                                                                          \
+    hipLaunchKernelGGL((k_wta<LN, NVV, true>), dim3(g.H, 1), dim3(256), lds, st, reinterpret_cast<const uint16_t*>(L), \
+                       dst, (size_t)g.W, (size_t)0, g, (size_t)0, nd, sd.dir_stride, tie_lanes, combine, h->cost_neg, vp)
+    if (g.lanes == 2) CAMD_XWTA(2, 1);
+    else if (g.lanes == 4) CAMD_XWTA(4, 1);
+    else if (g.lanes == 8) CAMD_XWTA(8, 1);
+    else if (g.nv == 1) CAMD_XWTA(16, 1);
+    else if (g.nv == 2) CAMD_XWTA(16, 2);
+    else if (g.nv == 3) CAMD_XWTA(16, 3);
+    else CAMD_XWTA(16, 4);
+#undef CAMD_XWTA
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
 }  // namespace camd
 
 using namespace camd;
@@ -944,7 +1077,7 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     size_t vol = align_up((size_t)vrows * w1 * g.Dp * 2, 256);
     size_t raw = align_up((size_t)height * width * 2, 256);
     size_t total = (size_t)max_batch * (2 * cr.n * vol + raw);
-    total += (size_t)max_batch * cr.n * 4;  // per-volume flags of the two-stage saturating cost build
+    total += (size_t)max_batch * cr.n * 8 + 8;  // per-volume flags (near-overflow, below-P2), ticket + error word
     if (way3) total += (size_t)max_batch * cr.n * align_up((size_t)vrows * width * 2, 256);
     if (g.speckleWindowSize > 0) total += speckle_ws_bytes(width, height, max_batch);
     const bool band_ok = band_supported(g);
@@ -952,9 +1085,12 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
         const int R = BAND_THREADS / g.lanes;
         size_t nb = (size_t)div_up(vrows, R);
         total += (size_t)max_batch * cr.n * nb * (band_erec_stride(g.W1, g.lanes, g.nv) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
-        total += (size_t)max_batch * cr.n * vrows * width * 6 + 8;
+        total += (size_t)max_batch * cr.n * vrows * width * 6;
     }
-    if (!way3) total += (size_t)g.npaths * auto_concurrent_pairs(g, band_ok, max_batch) * vol;  // per-direction volumes (latency path)
+    // per-direction volumes: the latency path's, and one set of int volumes for the exact aggregation where the
+    // parameters allow an int16 overflow of the cost volume (sgbm_exact.hpp)
+    if (!way3) total += (size_t)g.npaths * auto_concurrent_pairs(g, band_ok, max_batch) * vol;
+    if (w1 > 0 && params_may_overflow(g)) total += (size_t)g.npaths * vol * 2;
     return total;
 }
 
@@ -998,7 +1134,15 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         if (e == hipSuccess && way3) e = hipMalloc((void**)&h->rawv, nvol * align_up((size_t)vrows * width * 2, 256));
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->raw, (size_t)max_batch * raw_e * 2);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->cost_ovf, nvol * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->cost_ovf, nvol * 8);
+    h->cost_neg = h->cost_ovf ? h->cost_ovf + nvol : nullptr;
+    if (e == hipSuccess) e = hipMemset(h->cost_ovf, 0, nvol * 8);
+    h->may_overflow = params_may_overflow(g);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->ticket, 8);
+    if (e == hipSuccess) e = hipMemset(h->ticket, 0, 8);
+    h->err = h->ticket ? h->ticket + 1 : nullptr;
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->err_host, 4, hipHostMallocDefault);
+    if (e == hipSuccess) *h->err_host = 0;
     size_t sws = speckle_ws_bytes(width, height, max_batch);
     if (e == hipSuccess && g.speckleWindowSize > 0) e = hipMalloc(&h->speckle_ws, sws);
     h->band_ok = band_supported(g);
@@ -1014,18 +1158,27 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         size_t npix = nvol * vrows * width;  // the winner-take-all state of every (virtual) pair
         if (e == hipSuccess) e = hipMalloc((void**)&h->E, nvol * h->nbands * h->erec_stride * 8);
         if (e == hipSuccess) e = hipMalloc((void**)&h->flags, nflags * 4);
-        if (e == hipSuccess) e = hipMalloc((void**)&h->ticket, 8);
         if (e == hipSuccess) e = hipMalloc((void**)&h->keys, npix * 4);
         if (e == hipSuccess) e = hipMalloc((void**)&h->d1, npix * 2);
         if (e == hipSuccess) e = hipMemset(h->flags, 0, nflags * 4);
-        if (e == hipSuccess) e = hipMemset(h->ticket, 0, 8);
-        h->err = h->ticket + 1;
-        if (e == hipSuccess) e = hipHostMalloc((void**)&h->err_host, 4, hipHostMallocDefault);
-        if (e == hipSuccess) *h->err_host = 0;
     }
-    h->smulti_cap = w1 > 0 && !way3 ? auto_concurrent_pairs(g, h->band_ok, max_batch) : 0;
-    if (e == hipSuccess && h->smulti_cap > 0)
-        e = hipMalloc((void**)&h->Smulti, (size_t)g.npaths * h->smulti_cap * h->vol_elems * 2);
+    // per-direction volumes, allocated last and allowed to fail: the latency path then has fewer pairs (or none: the
+    // sequential scans take over), and without the one set the exact aggregation needs a flagged volume is refused
+    // loudly (k_poison_flagged) instead
+    if (e == hipSuccess && w1 > 0) {
+        int cap = way3 ? 0 : auto_concurrent_pairs(g, h->band_ok, max_batch);
+        while (cap > 0) {
+            if (hipMalloc((void**)&h->Smulti, (size_t)g.npaths * cap * h->vol_elems * 2) == hipSuccess) break;
+            (void)hipGetLastError();
+            h->Smulti = nullptr;
+            cap /= 2;
+        }
+        h->smulti_cap = cap;
+        if (h->may_overflow) {
+            if (hipMalloc((void**)&h->Lx, (size_t)g.npaths * h->vol_elems * 4) == hipSuccess) h->exact_cap = 1;
+            else { (void)hipGetLastError(); h->Lx = nullptr; }
+        }
+    }
     if (e != hipSuccess) {
         set_error("workspace allocation failed: %s", hipGetErrorString(e));
         camd_sgbm_destroy(h);
@@ -1033,6 +1186,17 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     }
     *out = h;
     return CAMD_OK;
+}
+
+// what the bits of the device-side error word mean (camd_sgbm_status / the next compute report them)
+static const char* device_error_text(uint32_t e)
+{
+    if (e & 2u)
+        return "a cost volume left the int16 regime of the aggregation kernels (values below P2 after an overflow of the "
+               "box sums) and the handle has no workspace for the exact path; the disparities of that pair were written "
+               "as invalid";
+    return "a band-wavefront pass timed out waiting for its upstream band; the disparities of that call were written as "
+           "invalid";
 }
 
 int camd_sgbm_destroy(camd_sgbm* h)
@@ -1043,7 +1207,7 @@ int camd_sgbm_destroy(camd_sgbm* h)
     (void)hipFree(h->C); (void)hipFree(h->S);
     (void)hipFree(h->raw); (void)hipFree(h->rawv); (void)hipFree(h->speckle_ws); (void)hipFree(h->cost_ovf);
     (void)hipFree(h->E); (void)hipFree(h->flags); (void)hipFree(h->ticket); (void)hipFree(h->keys);
-    (void)hipFree(h->d1); (void)hipFree(h->Smulti);
+    (void)hipFree(h->d1); (void)hipFree(h->Smulti); (void)hipFree(h->Lx);
     if (h->err_host) (void)hipHostFree(h->err_host);
     delete h;
     return CAMD_OK;
@@ -1087,6 +1251,7 @@ int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
     else if (option == CAMD_OPT_COST && value >= CAMD_COST_AUTO && value <= CAMD_COST_SPLIT) h->cost_path = value;
     else if (option == CAMD_OPT_SATURATE) h->saturate = value != 0;
     else if (option == CAMD_OPT_3WAY_SIMD_LANES && (value == 1 || value == 8)) h->way3_simd_lanes = value;
+    else if (option == CAMD_OPT_EXACT) h->exact_cap = (value != 0 && h->Lx) ? 1 : 0;
     else { set_error("unknown option %d / value %d", option, value); return CAMD_ERR_BAD_ARG; }
     return CAMD_OK;
 }
@@ -1101,8 +1266,7 @@ int camd_sgbm_status(camd_sgbm* h, void* stream)
     if (e) {
         CAMD_HIP(hipMemsetAsync(h->err, 0, 4, (hipStream_t)stream));
         if (h->err_host) *(volatile uint32_t*)h->err_host = 0;
-        set_error("a band-wavefront pass timed out waiting for its upstream band; the disparities of that call "
-                  "were written as invalid");
+        set_error("%s", device_error_text(e));
         return CAMD_ERR_HIP;
     }
     return CAMD_OK;
@@ -1148,10 +1312,10 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     // k_lrcheck) is reported here without a synchronisation: the flag travels through a pinned mirror that an
     // async copy refreshes at the end of every band-path compute.
     if (h->err_host && *(volatile uint32_t*)h->err_host) {
+        const uint32_t e = *(volatile uint32_t*)h->err_host;
         *(volatile uint32_t*)h->err_host = 0;
         CAMD_HIP(hipMemsetAsync(h->err, 0, 4, st));
-        set_error("an earlier compute on this handle timed out in a band-wavefront pass (its disparities were "
-                  "written as invalid)");
+        set_error("in an earlier compute on this handle: %s", device_error_text(e));
         return CAMD_ERR_HIP;
     }
     const size_t dpe = disp_pitch / 2, dse = disp_stride / 2;
@@ -1171,7 +1335,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     // ---- matching cost volume C ------------------------------------------------------------------------------
     const int K = 2 * g.SW2 + 1;
     // U7: int16 overflow is possible at all only beyond this bound; below it SAT == wrap
-    const bool may_overflow = (long long)K * K * g.cn * (2 * g.ftzero + 63) + g.P2 > 32767;
+    const bool may_overflow = h->may_overflow;
     const bool sat = h->saturate && may_overflow;
     const bool way3 = g.mode == CAMD_MODE_SGBM_3WAY;
     const int vbatch = batch * h->cr.n;  // volumes this call fills (3WAY: four stripes per pair)
@@ -1204,7 +1368,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
             const size_t lds = cost_lds_bytes(g.cn, nw);
 #define CAMD_COST(CNN, KK, SS)                                                                                       \
     hipLaunchKernelGGL((k_cost<CNN, KK, SS>), grid, block, lds, st, left, right, pitch, image_stride, h->C, g, rb, \
-                       nchunks, h->vol_elems, h->cr, ovf, thresh)
+                       nchunks, h->vol_elems, h->cr, ovf, thresh, h->cost_neg)
 #define CAMD_COST_K(CNN)                                                                         \
     switch (K) {                                                                                 \
         case 1: CAMD_COST(CNN, 1, false); break;                                                 \
@@ -1218,6 +1382,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
 #undef CAMD_COST_K
 #undef CAMD_COST
         };
+        if (may_overflow) CAMD_HIP(hipMemsetAsync(h->cost_neg, 0, (size_t)vbatch * 4, st));
         if (two_stage) {
             CAMD_HIP(hipMemsetAsync(h->cost_ovf, 0, (size_t)vbatch * 4, st));
             launch_cost(false, h->cost_ovf, 32767 - tbound);
@@ -1277,6 +1442,16 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
                     hipLaunchKernelGGL(k_vsum<false>, vgrid, dim3(256), ring_lds, st, hs4, c4, g, h->vol_elems / 8, VSUM_ROWS);
             }
         }
+        CAMD_LAUNCH_CHECK();
+    }
+
+    // Volumes that hold a value below P2 are outside the regime of the packed-u16 aggregation kernels (sgbm_exact.hpp).
+    // The saturating cost kernel reports them itself; behind the wrapping kernels and the split pair one more pass over
+    // C finds them (only where the parameters allow an overflow at all)
+    if (may_overflow && !(fused && sat)) {
+        if (!fused) CAMD_HIP(hipMemsetAsync(h->cost_neg, 0, (size_t)vbatch * 4, st));
+        hipLaunchKernelGGL(k_flag_below, dim3(512, 1, vbatch), dim3(256), 0, st, reinterpret_cast<const int16_t*>(h->C),
+                           h->ga, h->vol_elems, h->cr, h->cost_neg);
         CAMD_LAUNCH_CHECK();
     }
 
@@ -1356,6 +1531,25 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         MARK(ST_SCAN2);  // (no separate last pass on the scan paths: zero-length stage)
     }
 
+    // Volumes flagged as outside the u16 regime are aggregated again in int arithmetic, one at a time through the one
+    // set of per-direction volumes (two launches per volume that return at once for the others), and their raw
+    // disparities replaced; without that workspace they are written as invalid and reported.
+    auto exact_redo = [&](int16_t* dst, size_t stride_e, size_t n_e, int nvolumes) -> int {
+        if (!may_overflow) return CAMD_OK;
+        if (!h->exact_cap) {
+            hipLaunchKernelGGL(k_poison_flagged, dim3(64, nvolumes), dim3(256), 0, st, dst, stride_e, n_e, h->cost_neg,
+                               h->err, (g.minD - 1) * 16);
+            CAMD_LAUNCH_CHECK();
+            CAMD_HIP(hipMemcpyAsync(h->err_host, h->err, 4, hipMemcpyDeviceToHost, st));
+            return CAMD_OK;
+        }
+        for (int vp = 0; vp < nvolumes; vp++) {
+            int rc = launch_exact(h, vp, dst + (size_t)vp * stride_e, st);
+            if (rc != CAMD_OK) return rc;
+        }
+        return CAMD_OK;
+    };
+
     MARK(ST_WTA);
     if (band && !way3) {
         hipLaunchKernelGGL(k_lrcheck, dim3(div_up(g.W, 256), g.H, batch), dim3(256), 0, st, h->d1, h->keys, h->raw,
@@ -1373,6 +1567,10 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
             int rc = launch_wta(h, h->S, 1, 0, h->rawv, (size_t)g.W, rawv_stride, vbatch, st);
             if (rc != CAMD_OK) return rc;
         }
+        {
+            int rc = exact_redo(h->rawv, rawv_stride, (size_t)h->ga.H * g.W, vbatch);
+            if (rc != CAMD_OK) return rc;
+        }
         hipLaunchKernelGGL(k_gather_stripes, dim3(div_up(g.W, 256), g.H, batch), dim3(256), 0, st, h->rawv, rawv_stride,
                            h->raw, raw_stride, g.W, g.H, h->stripe_sz, h->cr, band ? h->err : nullptr, (g.minD - 1) * 16);
         CAMD_LAUNCH_CHECK();
@@ -1380,6 +1578,11 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     } else {
         int rc = multi ? launch_wta(h, h->Smulti, g.npaths, dir_stride, h->raw, (size_t)g.W, raw_stride, batch, st)
                        : launch_wta(h, h->S, 1, 0, h->raw, (size_t)g.W, raw_stride, batch, st);
+        if (rc != CAMD_OK) return rc;
+    }
+
+    if (!way3) {
+        int rc = exact_redo(h->raw, raw_stride, (size_t)g.H * g.W, batch);
         if (rc != CAMD_OK) return rc;
     }
 

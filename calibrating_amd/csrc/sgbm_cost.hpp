@@ -107,7 +107,7 @@ template <int CN, int K, bool SAT>
 __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
                                                Geom g, int rb, int nchunks, size_t vol_stride, CostRanges cr,
-                                               uint32_t* __restrict__ ovf, int ovf_thresh)
+                                               uint32_t* __restrict__ ovf, int ovf_thresh, uint32_t* __restrict__ neg)
 {
     constexpr int DL = COST_DL;
     constexpr int ES = CN == 1 ? 4 : 12;  // dwords per staged entry: (p, lo, hi) per channel, padded to 16 bytes
@@ -128,6 +128,9 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     // volumes whose flag is up
     if (SAT && ovf && !ovf[vpair]) return;
     uint32_t ovf_max = 0;
+    // SAT also reports (neg[volume]) whether a value it wrote is below P2: after a clipped sum the recurrence keeps what
+    // it lost, and a volume with C < P2 is outside the regime of the packed-u16 aggregation kernels (sgbm_exact.hpp)
+    uint32_t neg_min = SENT_PK;
     const int W1 = g.W1, H = g.H;
     const int xo0 = blockIdx.x * XS, xs0 = xo0 - SW2;                 // first output column, column of lane 0
     const int cmin = max(xs0, 0), cmax = min(xs0 + 63, W1 - 1);       // clamped column range of the strip
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
                     const int y = y0 + r - (K - 1);
                     uint4* o = reinterpret_cast<uint4*>(outp + (size_t)y * W1 * g.Dp);
                     *o = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                    if (SAT) neg_min = pk_min_i16(pk_min_i16(neg_min, pk_min_i16(acc[0], acc[1])), pk_min_i16(acc[2], acc[3]));
                     if (!SAT && ovf_thresh >= 0)  // (uniform)
                         ovf_max = pk_max_u16(pk_max_u16(ovf_max, pk_max_u16(acc[0], acc[1])), pk_max_u16(acc[2], acc[3]));
                 }
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
         }
     }
     if (!SAT && ovf_thresh >= 0 && (int)max(ovf_max & 0xffffu, ovf_max >> 16) > ovf_thresh) atomicOr(ovf + vpair, 1u);
+    if (SAT && neg && min((int)(int16_t)(neg_min & 0xffffu), (int)(int16_t)(neg_min >> 16)) < g.P2) atomicOr(neg + vpair, 1u);
 }
 
 }  // namespace camd

@@ -46,8 +46,11 @@ class StereoSGBM:
         2 = k_hsum + k_vsum (two passes through an intermediate volume).  All choices are bit-identical;
         'saturate': int16 overflow of the cost-volume sums, 1 = saturate like cv2's SIMD build (default),
         0 = wrap like OpenCV's scalar build (differs only for blockSize >= 7 on extreme images);
-        'way3_simd_lanes': MODE_SGBM_3WAY's tie rule, 8 = cv2's SSE / NEON builds (default), 1 = scalar build."""
-        opt = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3, "way3_simd_lanes": 4}[option]
+        'way3_simd_lanes': MODE_SGBM_3WAY's tie rule, 8 = cv2's SSE / NEON builds (default), 1 = scalar build;
+        'exact': a pair whose cost volume left the int16 regime of the fast kernels (only after an overflow of the box
+        sums on adversarial images) is 1 = aggregated again in plain int arithmetic (default), 0 = refused (written
+        as invalid, status() / the next compute raise)."""
+        opt = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3, "way3_simd_lanes": 4, "exact": 5}[option]
         self._options[opt] = int(value)
         if self._handle is not None:
             _native.check(_native.lib().camd_sgbm_set_option(self._handle, opt, int(value)))

@@ -51,6 +51,23 @@ def rectified_pair(seed=1234, H=1080, W=1920, D=128, cn=1):
     return left, right
 
 
+def drift_pair(H, W, cn=3, split=0.5, seed=0):
+    """An adversarial pair for the int16 regime of the cost volume: opposite sawtooth ramps in the upper part (every
+    pixel cost at its maximum: with a large block and preFilterCap the box sums overflow int16), identical random
+    texture below (pixel cost 0).  The recurrence that builds C keeps what it lost in the overflow, so below the split
+    C falls under P2 or turns negative -- the regime in which OpenCV's int arithmetic and packed u16 part ways."""
+    x, y = np.arange(W)[None, :], np.arange(H)[:, None]
+    ramp = ((x * 16 + y * 40) % 256).astype(np.uint8)
+    left, right = ramp.copy(), 255 - ramp
+    h0 = int(H * split)
+    tex = np.random.default_rng(seed).integers(0, 256, (H, W), dtype=np.uint8)
+    left[h0:] = tex[h0:]
+    right[h0:] = tex[h0:]
+    if cn == 3:
+        left, right = left[..., None].repeat(3, 2), right[..., None].repeat(3, 2)
+    return left, right
+
+
 def rodrigues(r):
     """cv2.Rodrigues(vector) -> 3x3."""
     r = np.asarray(r, np.float64).reshape(3)

@@ -86,7 +86,8 @@ int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* st
  * 1080p/D=128-sized work) and the band passes above; CAMD_PATH_BAND / CAMD_PATH_CONCURRENT force the band passes
  * (where D allows; the winners are decided inside the last pass for D % 8 == 0, by a separate kernel otherwise).
  * CAMD_OPT_KEEP_S 1 = the band path also stores the final S volume (for camd_sgbm_debug_copy(which = 1)). */
-enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1, CAMD_OPT_COST = 2, CAMD_OPT_SATURATE = 3, CAMD_OPT_3WAY_SIMD_LANES = 4 };
+enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1, CAMD_OPT_COST = 2, CAMD_OPT_SATURATE = 3, CAMD_OPT_3WAY_SIMD_LANES = 4,
+       CAMD_OPT_EXACT = 5 };
 enum { CAMD_PATH_AUTO = 0, CAMD_PATH_SCAN = 1, CAMD_PATH_BAND = 2, CAMD_PATH_CONCURRENT = 3 };
 /* CAMD_OPT_COST selects how the matching-cost volume C is built (bit-identical results):
  *   CAMD_COST_AUTO (default)  the fused kernel where it is instantiated (blockSize <= 11), else the split pair
@@ -100,11 +101,19 @@ enum { CAMD_COST_AUTO = 0, CAMD_COST_FUSED = 1, CAMD_COST_SPLIT = 2 };
  * window sum past 32767 (e.g. blockSize >= 11 on RGB with a large preFilterCap).
  * CAMD_OPT_3WAY_SIMD_LANES (MODE_SGBM_3WAY only): 8 (default) = the winner-take-all tie rule of cv2's 8-lane SIMD builds
  * (per lane slot the last disparity attaining the slot minimum, then the smallest of those), 1 = the scalar build's
- * smallest disparity.  Only exact ties are affected. */
+ * smallest disparity.  Only exact ties are affected.
+ * CAMD_OPT_EXACT: what happens to a pair whose cost volume left the int16 regime of the aggregation kernels (a value
+ * below P2, possible only after an int16 overflow of the box sums, i.e. only when blockSize^2 * channels *
+ * (2*ftzero + 63) + P2 > 32767 and the images are adversarial):
+ *   1 (default)  it is aggregated again in plain int arithmetic, exactly as OpenCV's scalar code does (slow, one set
+ *                of per-direction volumes of workspace)
+ *   0            it is refused: its disparities are written as invalid and camd_sgbm_status / the next
+ *                camd_sgbm_compute return CAMD_ERR_HIP (also what happens when that workspace could not be allocated)
+ * Either way a result that differs from OpenCV's is never handed back silently. */
 int camd_sgbm_set_option(camd_sgbm* h, int option, int value);
-/* synchronises `stream` and reports whether a device-side bounded wait of the last computes timed out.
- * Without this call a timeout still cannot pass unnoticed: the affected call's disparities are written as
- * all-invalid ((minDisparity - 1) * 16), and the next camd_sgbm_compute on the handle returns CAMD_ERR_HIP. */
+/* synchronises `stream` and reports whether a device-side bounded wait of the last computes timed out, or a pair
+ * was refused (CAMD_OPT_EXACT).  Without this call neither can pass unnoticed: the affected disparities are written as
+ * invalid ((minDisparity - 1) * 16), and the next camd_sgbm_compute on the handle returns CAMD_ERR_HIP. */
 int camd_sgbm_status(camd_sgbm* h, void* stream);
 /* per-stage GPU time of the last compute, measured with hipEvents on `stream` (enable first).
  * stage names: camd_sgbm_stage_name(i), i in [0, camd_sgbm_num_stages()) */
