@@ -91,6 +91,79 @@ def rig(W=1280, H=720):
     )
 
 
+def _undistort_points(xd, yd, dist, iters=40):
+    """Normalised distorted -> ideal coordinates under the Brown model (k1 k2 p1 p2 k3): the fixed-point iteration of
+    cv2.undistortPoints, run to convergence."""
+    k1, k2, p1, p2, k3 = (list(np.asarray(dist, np.float64).reshape(-1)) + [0.0] * 5)[:5]
+    x, y = xd.copy(), yd.copy()
+    for _ in range(iters):
+        r2 = x * x + y * y
+        radial = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x, y = (xd - dx) / radial, (yd - dy) / radial
+    return x, y
+
+
+def plane_texture(a, b, cn=3, seed=0):
+    """Analytic band-limited texture on a plane: a, b = plane coordinates in metres.  A sum of sinusoids with
+    wavelengths of 2.5 .. 25 cm in random directions (no sampling, no interpolation); uint8 (..., cn)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(a.shape + (cn,), np.float64)
+    for c in range(cn):
+        acc = np.zeros(a.shape)
+        n = 14
+        for k in range(n):
+            wl = 0.025 * (10.0 ** rng.uniform(0, 1))
+            th, ph = rng.uniform(0, 2 * np.pi), rng.uniform(0, 2 * np.pi)
+            acc += np.sin(2 * np.pi / wl * (np.cos(th) * a + np.sin(th) * b) + ph)
+        out[..., c] = 127.5 + acc * (120.0 / np.sqrt(n) / 2.2)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def render_plane_pair(rig_rec, normal=(0.0, 0.0, 1.0), distance=2.0, cn=3, seed=0):
+    """Ground truth for the whole depth path, independent of any remap or matcher code: a textured plane
+    {X : n.X = n.(0, 0, distance)} (camera-1 coordinates, metres) rendered into both cameras of the rig record by
+    per-pixel ray casting through the full Brown model -- pixel -> normalised distorted coordinates -> iterative
+    undistortion -> ray -> plane -> analytic texture (plane_texture); nothing is interpolated.
+
+    Returns (img1, img2, z_true) with z_true(v, u) = the depth along camera 1's optical axis of what the IDEAL
+    (undistorted, intrinsics K1) camera 1 sees at pixel (u, v): the frame Stereo.unrectify_depth reports in
+    (/root/reference/calibrating/stereo_camera.py:415-428)."""
+    R = np.asarray(rig_rec["R"], np.float64)
+    t = np.asarray(rig_rec["t"], np.float64).reshape(3)  # X2 = R X1 + t
+    n = np.asarray(normal, np.float64)
+    n = n / np.linalg.norm(n)
+    d0 = n[2] * distance
+    e1 = np.cross([0.0, 1.0, 0.0], n)
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(n, e1)
+
+    def rays(cam, distorted=True):
+        K = np.asarray(cam["K"], np.float64)
+        w, h = cam["xy"]
+        v, u = np.mgrid[:h, :w].astype(np.float64)
+        x, y = (u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1]
+        if distorted:
+            x, y = _undistort_points(x, y, cam["D"])
+        return np.stack([x, y, np.ones_like(x)], -1)
+
+    def shade(X1):
+        return plane_texture(X1 @ e1, X1 @ e2, cn, seed)
+
+    r1 = rays(rig_rec["cam1"])
+    img1 = shade(r1 * (d0 / (r1 @ n))[..., None])
+    r2 = rays(rig_rec["cam2"]) @ R                     # R^T r2: the ray direction in camera-1 coordinates
+    o2 = -R.T @ t                                       # camera 2's centre in camera-1 coordinates
+    s2 = (d0 - n @ o2) / (r2 @ n)
+    img2 = shade(o2 + r2 * s2[..., None])
+    ri = rays(rig_rec["cam1"], distorted=False)
+    z_true = d0 / (ri @ n)
+    if cn == 1:
+        img1, img2 = img1[..., 0], img2[..., 0]
+    return img1, img2, z_true
+
+
 def scene_pair(seed=7, W=1280, H=720, cn=3):
     """Unrectified-looking random textured pair for the full get_depth pipeline (content is
     arbitrary: the parity tests only need identical inputs on both sides)."""

@@ -25,9 +25,18 @@ def test_c4_4k_d256_full_size_properties():
     dev = torch.device("cuda", 0)
     L, R = synthetic.rectified_batch_torch(7, 2, 2160, 3840, 256, 1, dev)
     m = ca.StereoSGBM_create(**P)
+    m.set_option("path", 2)
     two = m.compute(L, R)                      # band passes
-    one = m.compute(L[:1], R[:1])              # concurrent scans
+    # (a 4K / D=256 pair is 8 units of work: AUTO would send the single pair down the band passes as well, so the
+    # second aggregation path is forced -- one line scan per direction, a different kernel and a different order)
+    m.set_option("path", 1)
+    one = m.compute(L[:1], R[:1])              # sequential line scans
     assert torch.equal(two[0], one[0])         # the two aggregation paths agree at full size
+    m8 = ca.StereoSGBM_create(**dict(P, mode=1))
+    m8.set_option("path", 2)
+    hh = m8.compute(L[:1], R[:1])
+    m8.set_option("path", 1)
+    assert torch.equal(hh, m8.compute(L[:1], R[:1]))  # ... and in the 8-path mode
     assert (two[:, :, :256] == -16).all()      # the left band has no match
     assert (two >= 0).float().mean() > 0.6
 
