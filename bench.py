@@ -62,6 +62,15 @@ def parse(argv=None):
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (other mode, gray, PCIe)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="strips in the CPU baseline sample (0 = two per thread)")
     ap.add_argument("--lib", default="", help="measurement only: load this build of libcalibrating_amd.so (A/B kernels)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 run: nccl (= RCCL, the product) or gloo (CPU; with --stub-compute)")
+    ap.add_argument("--stub-compute", action="store_true",
+                    help="TEST HOOK, no GPU: CPU tensors and a no-op matcher that returns a deterministic tensor, so that "
+                         "everything around the kernels -- sharding, process group, table broadcast / install, the timed "
+                         "region, the reductions, the JSON line -- runs end to end with N ranks on a CPU box "
+                         "(tests/test_parallel_cpu.py).  The line it prints is marked \"data\": \"stub\" and is not a measurement")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="time budget of the CPU baseline's thread sweep")
     return ap.parse_args(argv)
 
 
@@ -96,58 +105,121 @@ def stage_table(V, HW, cn, mode):
     }
 
 
-def cpu_baseline(a, params):
-    """The CPU oracle (scalar C port of cv2.StereoSGBM, oracle/sgbm_ref.c) on ALL of this host's cores."""
+def _host_topology():
+    """What bounds a host-side baseline on this box: usable CPUs, the cgroup CPU quota, sockets / NUMA nodes."""
+    import glob
+    info = {"os_cpu_count": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0))}
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        info["cgroup_cpu_max"] = "%s %s" % (q, per)
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            info["cgroup_cpu_max"] = "%d %d" % (q, per)
+            quota = None if q <= 0 else q / per
+        except Exception:
+            info["cgroup_cpu_max"] = None
+    info["cgroup_quota_cpus"] = quota
+    info["numa_nodes"] = len(glob.glob("/sys/devices/system/node/node[0-9]*")) or None
+    try:
+        pk = {open(f).read().strip() for f in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology/physical_package_id")}
+        cores = {(open(f.replace("core_id", "physical_package_id")).read().strip(), open(f).read().strip())
+                 for f in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology/core_id")}
+        info["sockets"], info["physical_cores"] = len(pk) or None, len(cores) or None
+    except Exception:
+        info["sockets"] = info["physical_cores"] = None
+    return info
+
+
+def cpu_baseline_worker(a):
+    """Runs in a process of its own (no torch, no GPU binding, its own OpenMP pool): the scalar C oracle on the host
+    cores, swept over thread counts.  Prints one JSON object."""
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))  # before the first OpenMP region creates its pool
+    except OSError:
+        pass
     import oracle
     from calibrating_amd import synthetic
     oracle.build()
-    ncpu = os.cpu_count() or 1
-    threads = ncpu
-    # bounded sample (~10-30 s of CPU work): full-width strips of a quarter of the rows (SGBM cost is linear in
-    # rows), one strip per thread; scaled back to whole pairs below
+    params = sgbm_params(a)
+    topo = _host_topology()
+    usable = topo["affinity_cpus"]
+    # bounded sample: full-width strips of a quarter of the rows (SGBM cost is linear in rows), ONE strip per
+    # thread, distinct data per strip; rates are scaled back to whole pairs.  Inputs and outputs exist (and are
+    # touched) before any clock starts; the oracle's own scratch is a few rows per thread in MODE_SGBM
     hs = max(a.height // 4, 16)
+    cap = usable
     if a.mode == "hh":  # the two-pass mode keeps two whole strip volumes per thread: bound the host memory (32 GB)
-        vol = 2 * 2 * hs * max(a.width - a.disparities, 1) * a.disparities
-        threads = max(1, min(threads, int(32e9 // vol)))
-    n = a.cpu_pairs or threads
+        cap = max(1, min(cap, int(32e9 // (2 * 2 * hs * max(a.width - a.disparities, 1) * a.disparities))))
+    counts = sorted({t for t in (1, 8, 16, 32, 64, 128, 256, usable) if t <= cap})
+    nmax = counts[-1]
     base_l, base_r = synthetic.rectified_pair(seed=1234, H=hs, W=a.width, D=a.disparities, cn=a.channels)
-    L = np.stack([np.roll(base_l, 17 * i, axis=0) for i in range(n)])  # distinct strips: vertical rolls
-    R = np.stack([np.roll(base_r, 17 * i, axis=0) for i in range(n)])
-    # this leg runs on ALL host CPUs: lift the binding to the GPU's NUMA node (hostio.bind_near_gpu) while it lasts --
-    # OpenMP threads inherit the affinity of the thread that starts them
-    bound = os.sched_getaffinity(0)
-    try:
-        os.sched_setaffinity(0, range(ncpu))
-    except OSError:
-        pass
-    usable = len(os.sched_getaffinity(0))
+    L = np.stack([np.roll(base_l, 17 * i, axis=0) for i in range(nmax)])
+    R = np.stack([np.roll(base_r, 17 * i, axis=0) for i in range(nmax)])
+    oracle.sgbm_compute_batch(L[:1, :32], R[:1, :32], nthreads=1, **params)  # (library paged in)
+    t_start = time.perf_counter()
+    sweep, secs = {}, {}
+    # one whole pair on one thread: the latency of the reference's one-pair-per-call surface (SURVEY.md 8d)
+    full_l, full_r = synthetic.rectified_pair(seed=1234, H=a.height, W=a.width, D=a.disparities, cn=a.channels)
     t0 = time.perf_counter()
-    oracle.sgbm_compute_batch(L, R, nthreads=threads, **params)
-    dt = time.perf_counter() - t0
-    # the port streams a volume per thread and is bound by host memory bandwidth long before it runs out of cores:
-    # a second, short sample on an eighth of the threads is reported beside the all-core figure
-    fewer = {}
-    if threads >= 16 and not a.cpu_pairs:
-        t8 = threads // 8
-        t1 = time.perf_counter()
-        oracle.sgbm_compute_batch(L[:t8], R[:t8], nthreads=t8, **params)
-        fewer = {str(t8): (t8 * hs / a.height) / (time.perf_counter() - t1)}
-    os.sched_setaffinity(0, bound)
-    pairs = n * hs / a.height
-    return dict(value=pairs / dt, unit="pairs/s", cores=threads, host_cpu_count=ncpu, kind="port",
-                pairs_per_s_at_fewer_threads=fewer,
-                sample="%d strips of %dx%d (= %.2f pairs of %dx%d) D=%d cn=%d mode=%s, scalar C port "
-                       "oracle/sgbm_ref.c, %d OpenMP threads across strips on %d usable CPUs (os.cpu_count() = %d), "
-                       "%.1f s; cv2 itself is not installed on this box"
-                       % (n, a.width, hs, pairs, a.width, a.height, a.disparities, a.channels, a.mode,
-                          threads, usable, ncpu, dt))
+    oracle.sgbm_compute(full_l, full_r, **params)
+    single_call_ms = (time.perf_counter() - t0) * 1e3
+    for t in counts:
+        if t > 1 and time.perf_counter() - t_start > a.cpu_budget_s:
+            break
+        t0 = time.perf_counter()
+        oracle.sgbm_compute_batch(L[:t], R[:t], nthreads=t, **params)
+        secs[t] = time.perf_counter() - t0
+        sweep[t] = (t * hs / a.height) / secs[t]
+    best = max(sweep, key=sweep.get)
+    one = sweep.get(1) or (1e3 / single_call_ms)
+    eff = sweep[best] / best / one
+    quota = topo["cgroup_quota_cpus"]
+    if eff >= 0.5:
+        why = "per-thread rate at the best point is %.2f of the single-thread rate" % eff
+    else:
+        why = ("per-thread rate at the best point is %.2f of the single-thread rate: " % eff) + (
+            "the container's cgroup CPU quota is %.1f CPUs (cpu.max = %s), far fewer than the %d CPUs it may be scheduled on"
+            % (quota, topo["cgroup_cpu_max"], usable) if quota and quota < best else
+            "%d hardware threads share %s physical cores (SMT) and the port's per-thread working set (a row of the "
+            "volume per buffer) competes for the shared caches" % (usable, topo.get("physical_cores")))
+    print(json.dumps(dict(
+        value=sweep[best], unit="pairs/s", cores=best, kind="port", single_call_ms=single_call_ms,
+        single_thread_pairs_per_s=one, per_thread_efficiency_at_best=eff, efficiency_note=why,
+        thread_sweep_pairs_per_s={str(k): v for k, v in sweep.items()},
+        thread_sweep_seconds={str(k): v for k, v in secs.items()}, host=topo,
+        sample="thread sweep %s, per point one 1920x%d strip per thread (= %.2f pairs each; rates scaled to whole %dx%d "
+               "pairs), D=%d cn=%d mode=%s, scalar C port oracle/sgbm_ref.c with OpenMP across strips, run in a "
+               "process of its own with the affinity mask lifted to all %d CPUs; best point = `value`; single_call_ms "
+               "= one whole pair on one thread; %.1f s in all; cv2 itself is not installed on this box"
+               % (sorted(sweep), hs, hs / a.height, a.width, a.height, a.disparities, a.channels, a.mode, usable,
+                  time.perf_counter() - t_start))))
 
 
-def gpu_steps(matcher, left, right, out, steps, warmup, distributed=False):
+def cpu_baseline(a, params):
+    """The CPU oracle (scalar C port of cv2.StereoSGBM, oracle/sgbm_ref.c) on this host's cores, in a subprocess:
+    this process is bound to the CPUs next to its GPU and shares an OpenMP pool with torch, neither of which a fair
+    host-side baseline should inherit."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--width", str(a.width), "--height",
+           str(a.height), "--disparities", str(a.disparities), "--block", str(a.block), "--channels", str(a.channels),
+           "--mode", a.mode, "--cpu-budget-s", str(a.cpu_budget_s)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OMP_NUM_THREADS")}
+    env["OMP_WAIT_POLICY"] = "passive"  # a finished team must not spin on CPUs the next, larger team needs
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    if p.returncode != 0 or not p.stdout.strip():
+        return dict(value=None, unit="pairs/s", cores=0, kind="port", sample="CPU baseline failed: " + p.stderr[-300:])
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def gpu_steps(matcher, left, right, out, steps, warmup, distributed=False, sync=None):
     """(seconds, {stage: ms summed over the timed steps}) -- parallel_pairs.timed_steps around compute()."""
     import torch
     from calibrating_amd.parallel_pairs import timed_steps
     stage_ms = {}
+    sync = sync or torch.cuda.synchronize
 
     def step():
         matcher.compute(left, right, out=out)
@@ -157,31 +229,34 @@ def gpu_steps(matcher, left, right, out, steps, warmup, distributed=False):
         for k, v in matcher.stage_times_ms().items():  # hipEvents on the compute stream, read after the fact
             stage_ms[k] = stage_ms.get(k, 0.0) + v
 
-    timed_steps(step, 0, warmup, torch.cuda.synchronize, False)
-    dt = timed_steps(timed_step, steps, 0, torch.cuda.synchronize, distributed)
+    timed_steps(step, 0, warmup, sync, False)
+    dt = timed_steps(timed_step, steps, 0, sync, distributed)
     return dt, stage_ms
 
 
-def pipelined_steps(matchers, streams, lefts, rights, outs, steps, warmup, distributed=False):
+def pipelined_steps(matchers, streams, lefts, rights, outs, steps, warmup, distributed=False, sync=None):
     """seconds for `steps` steps, step k on handle / stream k % len(matchers); nothing synchronises between steps."""
+    import contextlib
     import torch
     from calibrating_amd.parallel_pairs import timed_steps
     n = len(matchers)
     k = [0]
+    sync = sync or torch.cuda.synchronize
+    on = lambda st: torch.cuda.stream(st) if st is not None else contextlib.nullcontext()  # noqa: E731
     # set-up, not a step: the first compute on a handle touches its freshly allocated workspace (seconds for 80 GB),
     # so every set runs once before the W warm-up steps -- whatever W is
     for i in range(n):
-        with torch.cuda.stream(streams[i]):
+        with on(streams[i]):
             matchers[i].compute(lefts[i], rights[i], out=outs[i])
-    torch.cuda.synchronize()
+    sync()
 
     def step():
         i = k[0] % n
         k[0] += 1
-        with torch.cuda.stream(streams[i]):
+        with on(streams[i]):
             matchers[i].compute(lefts[i], rights[i], out=outs[i])
 
-    return timed_steps(step, steps, warmup, torch.cuda.synchronize, distributed)
+    return timed_steps(step, steps, warmup, sync, distributed)
 
 
 def pcie_inclusive(matcher, left, right, out, steps, streams=()):
@@ -232,10 +307,43 @@ def pcie_inclusive(matcher, left, right, out, steps, streams=()):
                 note="pinned host buffers, H2D + compute + D2H overlapped on 3 streams, %d steps of %d pairs" % (steps, nb))
 
 
+class StubMatcher:
+    """--stub-compute: stands in for StereoSGBM where there is no GPU.  compute() writes a deterministic function of
+    its inputs (so the checksum of checksums depends on every rank's shard) and does no stereo matching."""
+    def set_option(self, *_):
+        return self
+
+    def set_profiling(self, *_):
+        pass
+
+    def status(self):
+        pass
+
+    def stage_times_ms(self):
+        return {}
+
+    def compute(self, left, right, out=None):
+        import torch
+        v = (left[..., 0].to(torch.int16) - right[..., 0].to(torch.int16)) if left.dim() == 4 else \
+            (left.to(torch.int16) - right.to(torch.int16))
+        if out is None:
+            return v
+        out.copy_(v)
+        return out
+
+
+def stub_inputs(seed, n, H, W, cn):
+    import torch
+    g = torch.Generator().manual_seed(int(seed))
+    shape = (n, H, W, cn) if cn > 1 else (n, H, W)
+    return (torch.randint(0, 256, shape, generator=g, dtype=torch.uint8),
+            torch.randint(0, 256, shape, generator=g, dtype=torch.uint8))
+
+
 def self_launch(a):
     """--gpus N > 1 without a launcher: run N ranks of this script under torch.distributed.run."""
     import torch
-    have = torch.cuda.device_count()
+    have = a.gpus if a.stub_compute else torch.cuda.device_count()
     if have < a.gpus:
         sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to report a "
                          "multi-GPU number from fewer devices\n" % (a.gpus, have))
@@ -252,6 +360,8 @@ def self_launch(a):
 
 def main():
     a = parse()
+    if a.cpu_baseline_worker:
+        return cpu_baseline_worker(a)
     if a.gpus > 1 and "RANK" not in os.environ:
         self_launch(a)
     import torch
@@ -261,13 +371,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "RANK" in os.environ and a.gpus not in (1, world):
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
-    if local_rank >= torch.cuda.device_count():
-        sys.exit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    from calibrating_amd import hostio
-    cpus_near_gpu = hostio.bind_near_gpu(local_rank)
+    stub = a.stub_compute
+    if stub and a.backend != "gloo":
+        sys.exit("bench.py: --stub-compute is the CPU test hook and goes with --backend gloo")
+    if not stub and a.backend != "nccl":
+        sys.exit("bench.py: the product runs over RCCL (--backend nccl); gloo is for --stub-compute")
+    if stub:
+        dev, cpus_near_gpu = torch.device("cpu"), None
+        sync = lambda: None  # noqa: E731
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+        if local_rank >= torch.cuda.device_count():
+            sys.exit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        from calibrating_amd import hostio
+        cpus_near_gpu = hostio.bind_near_gpu(local_rank)
+        sync = torch.cuda.synchronize
     # CAMD_BENCH_FORCE_DIST=1 exercises the RCCL path (init, table broadcast, barrier, reductions) with a
     # single rank, e.g. under `python -m torch.distributed.run --nproc-per-node 1`
     distributed = world > 1 or (os.environ.get("CAMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
@@ -275,7 +395,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ["NCCL_DEBUG"] = os.environ.get("CAMD_NCCL_DEBUG", "WARN")  # keep RCCL's banner off stdout
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if a.lib:
         from calibrating_amd import _native
@@ -291,24 +414,28 @@ def main():
     nfl = max(1, min(a.in_flight, a.steps))
     lefts, rights, outs, matchers, streams = [], [], [], [], []
     for i in range(nfl):  # every batch in flight has its own inputs, handle (workspace), output and stream
-        l, r = synthetic.rectified_batch_torch(1234 + rank + 1000 * i, nb, a.height, a.width, a.disparities,
-                                               a.channels, dev)
-        m = ca.StereoSGBM_create(**params)
+        if stub:
+            l, r = stub_inputs(1234 + rank + 1000 * i, nb, a.height, a.width, a.channels)
+            m = StubMatcher()
+        else:
+            l, r = synthetic.rectified_batch_torch(1234 + rank + 1000 * i, nb, a.height, a.width, a.disparities,
+                                                   a.channels, dev)
+            m = ca.StereoSGBM_create(**params)
         m.set_option("path", a.path)
         m.set_option("cost", a.cost)
         lefts.append(l); rights.append(r); matchers.append(m)
         outs.append(torch.empty((nb, a.height, a.width), dtype=torch.int16, device=dev))
-        streams.append(torch.cuda.Stream(device=dev))
+        streams.append(None if stub else torch.cuda.Stream(device=dev))
     left, right, out, matcher = lefts[0], rights[0], outs[0], matchers[0]
 
     # (1) kernel characterisation: a few steps on ONE stream with the library's hipEvents around every kernel
     matcher.set_profiling(True)
     kprof = max(1, min(a.steps, 5))
-    dt1, stage_ms = gpu_steps(matcher, left, right, out, kprof, a.warmup)
+    dt1, stage_ms = gpu_steps(matcher, left, right, out, kprof, a.warmup, sync=sync)
     matcher.set_profiling(False)
     prof_steps = kprof
     # (2) the timed region: exactly --steps steps, `nfl` batches in flight, barrier + synchronize on both sides
-    dt = pipelined_steps(matchers, streams, lefts, rights, outs, a.steps, a.warmup, distributed)
+    dt = pipelined_steps(matchers, streams, lefts, rights, outs, a.steps, a.warmup, distributed, sync=sync)
     for m in matchers:
         m.status()  # raises if a device-side bounded wait timed out
     checksum = sum(int(o.to(torch.int64).sum().item()) for o in outs)
@@ -316,7 +443,8 @@ def main():
     value = agg["total_pairs"] / agg["seconds"]
     single_stream = nb * kprof / dt1
     del matchers[1:], lefts[1:], rights[1:], outs[1:], m, l, r  # (the loop variables hold the last set alive)
-    torch.cuda.empty_cache()  # (the host-link rate measured below drops when much more HBM is allocated)
+    if not stub:
+        torch.cuda.empty_cache()  # (the host-link rate measured below drops when much more HBM is allocated)
 
     rccl = None
     if distributed:
@@ -326,23 +454,31 @@ def main():
         rig_dict = synthetic.rig(a.width, a.height)
         bundle = ca.Stereo.load(rig_dict).table_bundle() if rank == 0 else None
         tables = broadcast_tables(bundle, dev, src=0)
-        torch.cuda.synchronize()
+        sync()
         t_bcast = time.perf_counter() - t0
         stereo = ca.Stereo.load(rig_dict).install_tables(tables, dev)
-        stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(params, max_size=max(a.width, a.height))),
-                                   max_depth=20.0)
-        imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(im)) for im in
-                            synthetic.scene_pair(77, a.width, a.height, 3)]).to(dev)
-        res = stereo.get_depth_batch(imgs[:1].repeat(2, 1, 1, 1), imgs[1:].repeat(2, 1, 1, 1))
-        dsum = int(torch.nan_to_num(res["unrectify_depth"]).mul(1e4).round().to(torch.int64).sum().item())
-        rccl = dict(backend="nccl (RCCL)", world_size=world, table_bytes=int(sum(t.numel() * t.element_size()
-                                                                                  for t in tables.values())),
+        if stub:
+            # no kernels to run the installed tables through: the checksum is taken over the tables as this rank's
+            # Stereo now holds them (what get_depth_batch would read)
+            held = stereo._tables(dev)
+            dsum = int(sum(torch.nan_to_num(held[k].to(torch.float64)).mul(16).round().to(torch.int64).sum().item()
+                           for k in sorted(held)))
+            res = imgs = None
+        else:
+            stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(params, max_size=max(a.width, a.height))),
+                                       max_depth=20.0)
+            imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(im)) for im in
+                                synthetic.scene_pair(77, a.width, a.height, 3)]).to(dev)
+            res = stereo.get_depth_batch(imgs[:1].repeat(2, 1, 1, 1), imgs[1:].repeat(2, 1, 1, 1))
+            dsum = int(torch.nan_to_num(res["unrectify_depth"]).mul(1e4).round().to(torch.int64).sum().item())
+        rccl = dict(backend="gloo (CPU stub)" if stub else "nccl (RCCL)", world_size=world,
+                    table_bytes=int(sum(t.numel() * t.element_size() for t in tables.values())),
                     broadcast_s=t_bcast, get_depth_checksum=dsum, ranks_agree=bool(ranks_agree(dsum, dev)),
                     per_rank=[dict(pairs=p, seconds=s, disparity_checksum=c) for p, s, c in agg["per_rank"]])
         del stereo, tables, res, imgs
 
     also = {}
-    if rank == 0 and world == 1 and not a.no_also:
+    if rank == 0 and world == 1 and not a.no_also and not stub:
         k2 = max(3, min(a.steps, 10))
         also["note"] = "every figure in `also` is measured with ONE batch in flight on one stream"
         also["single_stream_pairs_per_s"] = single_stream
@@ -423,7 +559,7 @@ def main():
             "metric": "stereo pairs/s at 1920x1080 numDisparities=128",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": agg["seconds"] / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16", "data": "stub" if stub else "synthetic",
             "config": {"workload": "cv2.StereoSGBM-equivalent disparity of %dx%d rectified %s pairs, "
                                    "numDisparities=%d blockSize=%d mode=%s, median3 on, speckle off"
                                    % (a.width, a.height, "RGB" if a.channels == 3 else "gray", a.disparities,
@@ -452,7 +588,9 @@ def main():
             line["also"] = also
         if rccl:
             line["rccl"] = rccl
-        if world == 1 and not a.no_cpu_baseline:
+        if stub:
+            line["stub"] = "TEST HOOK: CPU tensors and a no-op matcher; this line exercises the harness, it measures nothing"
+        if world == 1 and not a.no_cpu_baseline and not stub:
             line["cpu_baseline"] = cpu_baseline(a, params)
         print(json.dumps(line))
     if distributed:

@@ -24,7 +24,8 @@ CAMD_ERR_NOMEM = -5
 
 MODE_SGBM = 0
 MODE_HH = 1
-MODE_SGBM_3WAY = 2  # cv2's four-stripe, three-direction variant
+MODE_SGBM_3WAY = 2  # cv2's four-stripe, three-direction variant -- UNPINNED vs cv2: stripes, warm-up overlap and the SIMD
+                    # tie rule are restated from recollection; tools/export_cv2_golden.py settles them
 MODE_HH4 = 3
 INTER_NEAREST = 0
 INTER_LINEAR = 1

@@ -862,11 +862,11 @@ static double auto_concurrent_limit(const Geom& g) { return g.mode == CAMD_MODE_
 static int auto_concurrent_pairs(const Geom& g, bool band_ok, int max_batch)
 {
     int cap = max_batch < CAMD_MULTI_MAX_BATCH ? max_batch : CAMD_MULTI_MAX_BATCH;
-    if (band_ok) {
-        const int n = (int)(auto_concurrent_limit(g) / pair_work(g));
-        cap = n < cap ? n : cap;
-    }
-    return cap;
+    int n = (int)(auto_concurrent_limit(g) / pair_work(g));
+    // geometries without a band instantiation (D <= 32 or > 256) have no other fast path: the same work-based bound on
+    // the workspace (npaths volumes per pair), but never below one pair
+    if (!band_ok && n < 1) n = 1;
+    return n < cap ? n : cap;
 }
 
 // The band passes are instantiated for 16 lanes x {1,2} vectors and 8 lanes x 1 vector per pixel; their inline

@@ -8,8 +8,11 @@ additionally moves each result on a side stream as soon as its kernel has been q
 results (the rectified images) run underneath the later kernels (SGBM).  At 1080p the ~60 MB a ``get_depth`` call
 returns cost more wall time through pageable copies than all of its kernels.
 
-``PINNED = False`` falls back to plain ``.cpu()`` copies (for hosts where page-locked memory is rationed); calls that
-return more than ``PINNED_MAX_BYTES`` at once do so by themselves.
+``PINNED = False`` falls back to plain ``.cpu()`` copies (for hosts where page-locked memory is rationed); whatever a
+call returns beyond ``PINNED_MAX_BYTES`` takes plain copies by itself (``to_host`` and ``Sink`` alike).
+Ownership: every returned ndarray owns its page-locked block for as long as it lives (about 60 MB per 1080p
+``get_depth`` call, rounded up to powers of two by the allocator and returned to its cache, not to the OS, on collection);
+callers that keep many results around should copy what they keep (``np.array(x)``) or set ``PINNED = False``.
 """
 PINNED = True
 PINNED_MAX_BYTES = 1 << 30  # results larger than this in one call (big get_depth_batch calls) take plain copies
@@ -55,12 +58,19 @@ class Sink:
         self.main = torch.cuda.current_stream(device)
         self.side = _side_stream(device) if PINNED else None
         self.staged = {}
+        self.late = {}      # results beyond the PINNED_MAX_BYTES budget of this call: plain copies at collect()
+        self.pinned_bytes = 0
 
     def send(self, key, t):
         import torch
         if not PINNED:
             self.staged[key] = t
             return
+        nbytes = t.numel() * t.element_size()
+        if self.pinned_bytes + nbytes > PINNED_MAX_BYTES:
+            self.late[key] = t
+            return
+        self.pinned_bytes += nbytes
         self.side.wait_event(self.main.record_event())
         with torch.cuda.device(self.device), torch.cuda.stream(self.side):
             self.staged[key] = _start(t)
@@ -71,7 +81,9 @@ class Sink:
             return {k: t.cpu().numpy() for k, t in self.staged.items()}
         self.side.synchronize()
         self.main.synchronize()
-        return {k: h.numpy() for k, h in self.staged.items()}
+        out = {k: h.numpy() for k, h in self.staged.items()}
+        out.update({k: t.cpu().numpy() for k, t in self.late.items()})
+        return out
 
 
 def bind_near_gpu(index=0):

@@ -86,21 +86,17 @@ def aggregate(pairs_done, seconds, checksum, device, distributed=True):
                     per_rank=[(int(pairs_done), float(seconds), int(checksum))])
     import torch
     import torch.distributed as dist
-    # the checksum travels as two 31-bit halves so that float64 carries it exactly
-    cs = int(checksum)
-    mine = torch.tensor([float(pairs_done), float(seconds), float(cs & 0x7fffffff), float((cs >> 31) & 0x7fffffff)],
-                        dtype=torch.float64, device=device)
-    allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    n = dist.get_world_size()
+    mine = torch.tensor([float(pairs_done), float(seconds)], dtype=torch.float64, device=device)
+    allv = [torch.zeros_like(mine) for _ in range(n)]
     dist.all_gather(allv, mine)
-    rows = [(int(v[0].item()), float(v[1].item()), int(v[2].item()) | (int(v[3].item()) << 31)) for v in allv]
+    # the checksum travels as the int64 it is (sums of int16 disparities with many -16 pixels are negative)
+    cs = torch.tensor([int(checksum)], dtype=torch.int64, device=device)
+    allc = [torch.zeros_like(cs) for _ in range(n)]
+    dist.all_gather(allc, cs)
+    rows = [(int(v[0].item()), float(v[1].item()), int(c[0].item())) for v, c in zip(allv, allc)]
     return dict(total_pairs=sum(r[0] for r in rows), seconds=max(r[1] for r in rows),
                 checksum=sum(r[2] for r in rows), per_rank=rows)
-
-
-def gather_throughput(pairs_done, seconds, device):
-    """all_gather of per-rank (pairs, seconds); returns (total_pairs, max_seconds)."""
-    r = aggregate(pairs_done, seconds, 0, device, distributed=True)
-    return float(r["total_pairs"]), r["seconds"]
 
 
 def ranks_agree(value, device):
@@ -108,7 +104,6 @@ def ranks_agree(value, device):
     import torch
     import torch.distributed as dist
     v = int(value)
-    t = torch.tensor([v & 0x7fffffff, (v >> 31) & 0x7fffffff, -(v & 0x7fffffff), -((v >> 31) & 0x7fffffff)],
-                     dtype=torch.int64, device=device)
+    t = torch.tensor([v, -v], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return int(t[0].item()) == -int(t[2].item()) and int(t[1].item()) == -int(t[3].item())
+    return int(t[0].item()) == -int(t[1].item())

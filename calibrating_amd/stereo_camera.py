@@ -150,16 +150,22 @@ class Stereo:
         return type(self)().load(self.dump())
 
     def __str__(self):
-        rvec = geometry.rodrigues(self.R).reshape(3)
-        lines = ["Stereo(cam1='%s', cam2='%s'):" % (self.cam1.name, self.cam2.name),
-                 "\t xy: %s" % ", ".join(str(v) for v in self.cam1.xy),
-                 "\t baseline: %.2fcm" % (100 * self.baseline),
-                 "\t t(cm): [%s]" % " ".join(str(v) for v in (self.t.reshape(3) * 100).round(2)),
-                 "\t r(rodrigues): [%s] %.2f\u00b0" % (" ".join(str(v) for v in rvec.round(3)),
-                                                    np.degrees(np.linalg.norm(rvec)))]
-        lines.append("\t cam1.fovs: %s" % ", ".join("%s=%s\u00b0" % (k, round(v, 2)) for k, v in self.cam1.fovs.items()))
-        if hasattr(self, "retval"):
-            lines.append("\t retval: %s" % self.retval)
+        # like the reference's (stereo_camera.py:363-382) printing never raises: a rig loaded from a record without
+        # camera names / sizes still prints, with the failure appended
+        lines = []
+        try:
+            rvec = geometry.rodrigues(self.R).reshape(3)
+            lines.append("Stereo(cam1='%s', cam2='%s'):" % (getattr(self.cam1, "name", None), getattr(self.cam2, "name", None)))
+            lines += ["\t xy: %s" % ", ".join(str(v) for v in self.cam1.xy),
+                      "\t baseline: %.2fcm" % (100 * self.baseline),
+                      "\t t(cm): [%s]" % " ".join(str(v) for v in (self.t.reshape(3) * 100).round(2)),
+                      "\t r(rodrigues): [%s] %.2f\u00b0" % (" ".join(str(v) for v in rvec.round(3)),
+                                                          np.degrees(np.linalg.norm(rvec)))]
+            lines.append("\t cam1.fovs: %s" % ", ".join("%s=%s\u00b0" % (k, round(v, 2)) for k, v in self.cam1.fovs.items()))
+            if hasattr(self, "retval"):
+                lines.append("\t retval: %s" % self.retval)
+        except Exception as e:
+            lines.append("\t Exception(%s) in Stereo.__str__()" % e)
         return "\n".join(lines) + "\n"
 
     __repr__ = __str__
