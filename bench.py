@@ -37,7 +37,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PMC_PROFILE = "profiles/r02_pmc_traffic%s.json"  # committed rocprofv3 --pmc summary the `traffic` fields come from
+CLOCK_HZ, N_CUS = 2.4e9, 256  # MI355X peak engine clock and CUs: one VALU wave-instruction per CU and cycle (4 SIMD16s)
+
+
+def _latest_profile(pattern):
+    """The committed rocprofv3 --pmc summary of the most recent round that has one (profiles/rNN_<pattern>)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    return os.path.relpath(hits[-1], ROOT) if hits else None
 
 
 def parse(argv=None):
@@ -307,6 +314,84 @@ def pcie_inclusive(matcher, left, right, out, steps, streams=()):
                 note="pinned host buffers, H2D + compute + D2H overlapped on 3 streams, %d steps of %d pairs" % (steps, nb))
 
 
+def depth_path_rate(ca, synthetic, params, imgs1, imgs2, streams, W, H, D, cn, max_depth, reps):
+    """Stereo.get_depth_batch (rectify x2 -> SGBM -> disp_to_depth -> unrectify -> undistort) on `imgs1` / `imgs2`:
+    pairs/s with one batch at a time, and with two batches in flight (two rigs' worth of handles on two streams, as
+    the headline runs the matcher), plus the roofline of SURVEY.md 8(d): SGBM bytes + 81*H*W per pair."""
+    import torch
+    nb = imgs1.shape[0]
+    stereos = []
+    for _ in range(2):
+        st = ca.Stereo.load(synthetic.rig(W, H))
+        st.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(params, max_size=max(W, H))), max_depth=max_depth)
+        stereos.append(st)
+    pool = list(streams)[:2] + [torch.cuda.Stream() for _ in range(max(0, 2 - len(streams)))]
+    for i in range(2):  # set-up: tables, workspaces, allocator pools of both streams
+        with torch.cuda.stream(pool[i]):
+            stereos[i].get_depth_batch(imgs1, imgs2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        stereos[0].get_depth_batch(imgs1, imgs2)
+    torch.cuda.synchronize()
+    single = nb * reps / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for k in range(2 * reps):
+        with torch.cuda.stream(pool[k & 1]):
+            stereos[k & 1].get_depth_batch(imgs1, imgs2)
+    torch.cuda.synchronize()
+    double = nb * 2 * reps / (time.perf_counter() - t0)
+    for st in stereos:
+        st.stereo_matching.stereo_sgbm.status()
+    b_sgbm, _ = algorithmic_bytes_per_pair(W, H, D, cn)
+    b_alg = b_sgbm + 81 * W * H
+    return dict(pairs_per_s=double, single_stream_pairs_per_s=single, batches_in_flight=2, pairs_per_call=nb,
+                algorithmic_bytes_per_pair=b_alg, achieved_GBs=b_alg * double / 1e9,
+                frac=b_alg * double / 1e9 / HBM_PEAK_GBS,
+                note="rectify x2 (Lanczos-4) + SGBM + disp_to_depth + unrectify + undistort, device-resident RGB pairs; "
+                     "B_alg = 2V + IO + 81*H*W (SURVEY.md 8d)")
+
+
+def config_c4(ca, synthetic, dev, nb=16, reps=3):
+    """BASELINE.json configs[3]: 3840x2160 gray pairs, D=256, blockSize 5, MODE_SGBM, 16 pairs per call."""
+    import torch
+    W, H, D = 3840, 2160, 256
+    P = dict(minDisparity=0, numDisparities=D, blockSize=5, P1=8 * 25, P2=32 * 25, disp12MaxDiff=1, preFilterCap=0,
+             uniquenessRatio=10, speckleWindowSize=0, speckleRange=0, mode=0)
+    L, R = synthetic.rectified_batch_torch(7, nb, H, W, D, 1, dev)
+    m = ca.StereoSGBM_create(**P)
+    out = torch.empty((nb, H, W), dtype=torch.int16, device=dev)
+    m.compute(L, R, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.compute(L, R, out=out)
+    torch.cuda.synchronize()
+    rate = nb * reps / (time.perf_counter() - t0)
+    m.status()
+    b_alg, _ = algorithmic_bytes_per_pair(W, H, D, 1)
+    del m, L, R, out
+    torch.cuda.empty_cache()
+    return dict(workload="3840x2160 gray rectified pairs, numDisparities=256 blockSize=5 MODE_SGBM, %d pairs per call, "
+                         "one batch at a time" % nb, pairs_per_s=rate, algorithmic_bytes_per_pair=b_alg,
+                achieved_GBs=b_alg * rate / 1e9, frac=b_alg * rate / 1e9 / HBM_PEAK_GBS)
+
+
+def config_c5(ca, synthetic, dev, streams, nb=128):
+    """BASELINE.json configs[4]: 640x480 RGB, D=64, LR check on, speckle 100 / 2, the FULL get_depth path, batched."""
+    import torch
+    W, H, D = 640, 480, 64
+    P = dict(minDisparity=0, numDisparities=D, blockSize=5, P1=8 * 3 * 25, P2=32 * 3 * 25, disp12MaxDiff=1, preFilterCap=0,
+             uniquenessRatio=10, speckleWindowSize=100, speckleRange=2, mode=0)
+    pairs = [synthetic.scene_pair(100 + i, W, H, 3) for i in range(8)]
+    B1 = torch.from_numpy(np.stack([pairs[i % 8][0] for i in range(nb)])).to(dev)
+    B2 = torch.from_numpy(np.stack([pairs[i % 8][1] for i in range(nb)])).to(dev)
+    r = depth_path_rate(ca, synthetic, P, B1, B2, streams, W, H, D, 3, max_depth=3.5, reps=6)
+    r["workload"] = ("640x480 RGB pairs through the whole get_depth path (rectify x2, SGBM numDisparities=64 blockSize=5 "
+                     "LR check on speckle 100/2, disp_to_depth, unrectify, undistort), %d pairs per call" % nb)
+    return r
+
+
 class StubMatcher:
     """--stub-compute: stands in for StereoSGBM where there is no GPU.  compute() writes a deterministic function of
     its inputs (so the checksum of checksums depends on every rank's shard) and does no stereo matching."""
@@ -480,7 +565,8 @@ def main():
     also = {}
     if rank == 0 and world == 1 and not a.no_also and not stub:
         k2 = max(3, min(a.steps, 10))
-        also["note"] = "every figure in `also` is measured with ONE batch in flight on one stream"
+        also["note"] = ("figures named *_pairs_per_s are measured with ONE batch in flight on one stream; get_depth_batch, "
+                        "c4 and c5 say how they were run")
         also["single_stream_pairs_per_s"] = single_stream
         if os.environ.get("CAMD_BENCH_DEBUG"):
             free, total = torch.cuda.mem_get_info()
@@ -507,19 +593,15 @@ def main():
             also["gray_%s_pairs_per_s" % a.mode] = nb * k2 / d3
             del m3, gl, gr
             # the whole Stereo.get_depth path around the same matcher (rectify x2 -> SGBM -> disp_to_depth -> unrectify
-            # -> undistort) on a synthetic rig of the same size, one batch per call
+            # -> undistort) on a synthetic rig of the same size: one batch at a time, and double-buffered like the headline
             torch.cuda.empty_cache()
-            stereo = ca.Stereo.load(synthetic.rig(a.width, a.height))
-            stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(params, max_size=max(a.width, a.height))),
-                                       max_depth=20.0)
-            stereo.get_depth_batch(left, right)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                stereo.get_depth_batch(left, right)
-            torch.cuda.synchronize()
-            also["get_depth_batch_pairs_per_s"] = nb * 3 / (time.perf_counter() - t0)
-            del stereo
+            also["get_depth_batch"] = depth_path_rate(ca, synthetic, params, left, right, streams, a.width, a.height,
+                                                      a.disparities, 3, max_depth=20.0, reps=4)
+            also["get_depth_batch_pairs_per_s"] = also["get_depth_batch"]["pairs_per_s"]
+            del left, right, out, lefts, rights, outs
+            torch.cuda.empty_cache()
+            also["c4"] = config_c4(ca, synthetic, dev)
+            also["c5"] = config_c5(ca, synthetic, dev, streams)
 
     if rank == 0:
         b_alg, V = algorithmic_bytes_per_pair(a.width, a.height, a.disparities, a.channels)
@@ -528,17 +610,25 @@ def main():
         gpu_ms_step = agg["seconds"] / a.steps * 1e3             # the timed region (batches in flight overlap)
         # HBM traffic per kernel from the committed PMC profile of the same kernels (separate rocprofv3 --pmc
         # passes, 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction); null when no profile matches this workload
-        pmc_path = os.path.join(ROOT, PMC_PROFILE % ("_hh" if a.mode == "hh" else ""))
-        pmc = None
-        if (a.channels == 3 and (a.width, a.height, a.disparities, a.block) == (1920, 1080, 128, 5)
-                and os.path.exists(pmc_path)):
-            pmc = json.load(open(pmc_path))
+        pmc_rel = _latest_profile("pmc_traffic%s.json" % ("_hh" if a.mode == "hh" else ""))
+        sq_rel = _latest_profile("pmc_sq%s.json" % ("_hh" if a.mode == "hh" else ""))
+        pmc = sq = None
+        if a.channels == 3 and (a.width, a.height, a.disparities, a.block) == (1920, 1080, 128, 5):
+            pmc = json.load(open(os.path.join(ROOT, pmc_rel))) if pmc_rel else None
+            sq = json.load(open(os.path.join(ROOT, sq_rel))) if sq_rel else None
 
         def pmc_bytes_per_pair(keys):
             if not pmc:
                 return None
             hit = [v["hbm_bytes_per_pair"] for k, v in pmc["kernels"].items() if all(s in k for s in keys)]
             return hit[0] if len(hit) == 1 else None
+
+        def valu_insts_per_pair(keys):
+            """SQ_INSTS_VALU (wave-instructions) per pair from the committed SQ counter profile of the same kernel."""
+            if not sq:
+                return None
+            hit = [v.get("SQ_INSTS_VALU") for k, v in sq["kernels"].items() if all(s_ in k for s_ in keys)]
+            return hit[0] / sq["pairs_per_launch"] if len(hit) == 1 and hit[0] else None
 
         kernels = {}
         for st, ms_sum in stage_ms.items():
@@ -551,6 +641,13 @@ def main():
             kernels[st] = {"kernel": name, "avg_ms_per_launch": ms, "algorithmic_bytes_per_launch": float(per_pair * nb),
                            "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": (tr * nb) if tr is not None else None}
+            vi = valu_insts_per_pair(keys)
+            if vi is not None:
+                # VALU issue roofline: one wave-instruction per CU and cycle; the instruction count is a property of
+                # the kernel (counted once, committed), the duration is this run's
+                vf = vi * nb / (N_CUS * CLOCK_HZ) / (ms * 1e-3)
+                kernels[st].update(valu_wave_insts_per_launch=vi * nb, valu_frac=vf,
+                                   bound="valu" if vf >= max(0.5, ach / HBM_PEAK_GBS) else "hbm")
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms_per_launch"]) if kernels else None
         # whole-step traffic = every kernel of the committed PMC profile (incl. the small init / check kernels)
         traffic_total = sum(v["hbm_bytes_per_pair"] for v in pmc["kernels"].values()) * nb if pmc else None
@@ -571,7 +668,7 @@ def main():
             # the 8 TB/s HBM peak.  `kernels` / `dominant_kernel` characterise every kernel ALONE on the GPU (hipEvents
             # on the compute stream, a few single-stream steps before the timed region; `kernel_ms_per_step` = their
             # sum): the kernel with the largest launch duration, priced with ITS algorithmic bytes.  Every number can
-            # be recomputed from profiles/r02_*kernel_stats.csv and profiles/r02_pmc_traffic*.json.
+            # be recomputed from the latest profiles/rNN_*kernel_stats.csv, rNN_pmc_traffic*.json and rNN_pmc_sq*.json.
             "roofline": {
                 "bound": "hbm", "scope": "whole step (all kernels of one batch)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -579,7 +676,9 @@ def main():
                 "gpu_ms_per_step": gpu_ms_step, "kernel_ms_per_step": kernel_ms_step,
                 "traffic": traffic_total,
                 "traffic_ratio": (traffic_total / (b_alg * nb)) if traffic_total else None,
-                "traffic_source": (PMC_PROFILE % ("_hh" if a.mode == "hh" else "")) + " (bytes per pair per launch x pairs per launch)" if pmc else None,
+                "traffic_source": (pmc_rel + " (bytes per pair per launch x pairs per launch)") if pmc else None,
+                "valu_source": (sq_rel + " (SQ_INSTS_VALU per pair x pairs per launch / (%d CUs x %.1f GHz) / this run's "
+                                         "kernel time)" % (N_CUS, CLOCK_HZ / 1e9)) if sq else None,
                 "dominant_kernel": dict(kernels[dom], stage=dom) if dom else None,
                 "kernels": kernels,
             },

@@ -35,27 +35,37 @@ __global__ __launch_bounds__(256) void k_disp_to_depth(const int16_t* __restrict
     depth[o] = z;
 }
 
+// The images of a batch share the rig's maps: blockIdx.z owns `zb` consecutive images, so the map pair, the rounding
+// and the bounds test of a destination pixel are done once for all of them (8 of the 24 bytes per pixel and image).
 __global__ __launch_bounds__(256) void k_unrectify(const double* __restrict__ depth, int w, int h, double m0,
                                                    double m1, double m2, const float* __restrict__ mapx,
                                                    const float* __restrict__ mapy, double* __restrict__ out,
-                                                   int ow, int oh)
+                                                   int ow, int oh, int batch, int zb)
 {
     int x = blockIdx.x * 256 + threadIdx.x;
     int y = blockIdx.y;
     if (x >= ow) return;
+    const int z0 = blockIdx.z * zb, nz = min(zb, batch - z0);
     size_t mi = (size_t)y * ow + x;
     int sx = min(max(__float2int_rn(mapx[mi]), -32768), 32767);
     int sy = min(max(__float2int_rn(mapy[mi]), -32768), 32767);
-    double r = 0.;
-    if ((unsigned)sx < (unsigned)w && (unsigned)sy < (unsigned)h) {
-        double z = depth[(size_t)blockIdx.z * w * h + (size_t)sy * w + sx];
-        // M[2,0]*(x*z) + M[2,1]*(y*z) + M[2,2]*z, products and sums individually rounded
-        double a = __dmul_rn(m0, __dmul_rn((double)sx, z));
-        double b = __dmul_rn(m1, __dmul_rn((double)sy, z));
-        double c = __dmul_rn(m2, z);
-        r = __dadd_rn(__dadd_rn(a, b), c);
+    const bool inside = (unsigned)sx < (unsigned)w && (unsigned)sy < (unsigned)h;
+    const double* p = depth + (size_t)z0 * w * h + (inside ? (size_t)sy * w + sx : 0);
+    double* o = out + (size_t)z0 * ow * oh + mi;
+    const double fx = (double)sx, fy = (double)sy;
+#pragma unroll 4
+    for (int z = 0; z < nz; z++, p += (size_t)w * h, o += (size_t)ow * oh) {
+        double r = 0.;
+        if (inside) {
+            const double zz = *p;
+            // M[2,0]*(x*z) + M[2,1]*(y*z) + M[2,2]*z, products and sums individually rounded
+            double a = __dmul_rn(m0, __dmul_rn(fx, zz));
+            double b = __dmul_rn(m1, __dmul_rn(fy, zz));
+            double c = __dmul_rn(m2, zz);
+            r = __dadd_rn(__dadd_rn(a, b), c);
+        }
+        *o = r;
     }
-    out[(size_t)blockIdx.z * ow * oh + mi] = r;
 }
 
 }  // namespace camd
@@ -91,8 +101,10 @@ int camd_unrectify_depth(const double* depth, int w, int h, const double M[3], c
     }
     int rc = camd_device_ok();
     if (rc != CAMD_OK) return rc;
-    hipLaunchKernelGGL(k_unrectify, dim3(div_up(ow, 256), oh, batch), dim3(256), 0, (hipStream_t)stream, depth,
-                       w, h, M[0], M[1], M[2], mapx, mapy, out, ow, oh);
+    int zb = batch < 16 ? batch : 16;  // all images of the batch (up to 16) per workgroup while the grid fills the chip
+    while (zb > 1 && (long long)div_up(ow, 256) * oh * div_up(batch, zb) < 4096) zb = (zb + 1) / 2;
+    hipLaunchKernelGGL(k_unrectify, dim3(div_up(ow, 256), oh, div_up(batch, zb)), dim3(256), 0, (hipStream_t)stream,
+                       depth, w, h, M[0], M[1], M[2], mapx, mapy, out, ow, oh, batch, zb);
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
 }

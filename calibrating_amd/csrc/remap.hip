@@ -182,82 +182,167 @@ __device__ __forceinline__ void store_rounded(const int (&acc)[CN], uint8_t* out
     }
 }
 
-// one destination pixel: KS x KS taps at (ix, iy)..(ix+KS-1, iy+KS-1), weights w[KS*KS]
+// One row of a KS-wide window whose first byte is win[0]'s byte 0 (the interior path fetches the row from its own
+// byte address, so nothing has to be shifted into place); weights come from registers.
 template <int KS, int CN>
-__device__ __forceinline__ void gather_pixel(const uint8_t* __restrict__ src, int sw, int sh, size_t pitch,
-                                             int ix, int iy, const int16_t* __restrict__ w, uint8_t* out)
+__device__ __forceinline__ void mac_row_regs(const uint32_t (&win)[(KS * CN + 3) / 4 + 1], const uint32_t* wq,
+                                             int (&acc)[CN])
 {
-    int acc[CN];
 #pragma unroll
-    for (int c = 0; c < CN; c++) acc[c] = 0;
-    const bool interior = ix >= 3 && iy >= 0 && ix + KS + (CN == 1 ? 7 : 3) <= sw && iy + KS <= sh;
-    if (__all(interior)) {  // wave-uniform: a wave with any border lane takes the masked path below for all its lanes
-        // Interior fast path.  A row of the window is KS*CN consecutive bytes at an arbitrary address: fetch the
-        // aligned dwords that cover it (up to 3 bytes before and 7 bytes past it, hence the margins above) and
-        // hand them to mac_window_row.
-        constexpr int NW = (KS * CN + 3) / 4;
+    for (int q = 0; q < KS / 2; q++) {
 #pragma unroll
-        for (int r = 0; r < KS; r++) {
-            const uintptr_t pa = reinterpret_cast<uintptr_t>(src + (size_t)(iy + r) * pitch + (size_t)ix * CN);
-            const uint32_t* b = reinterpret_cast<const uint32_t*>(pa & ~(uintptr_t)3);
-            uint32_t raw[NW + 1];
-#pragma unroll
-            for (int j = 0; j <= NW; j++) raw[j] = b[j];
-            mac_window_row<KS, CN>(raw, (uint32_t)(pa & 3), w + r * KS, acc);
-        }
-    } else if (!(ix >= sw || ix + KS <= 0 || iy >= sh || iy + KS <= 0)) {
-        // The window crosses the image border (or sits too close to the ends of the buffer for the margins
-        // above).  Same arithmetic: rows outside the image are skipped and the window bytes left or right of
-        // the row are masked to the constant border 0, so what the dword fetches pick up there (the neighbouring
-        // row) does not matter; only where they would leave the image buffer itself -- first row near x = 0,
-        // last row near x = sw -- are they replaced by guarded byte loads.
-        constexpr int NW = (KS * CN + 3) / 4;
-        const int lo = max(0, -ix * CN), hi = min(KS * CN, (sw - ix) * CN);
-        const uintptr_t img_lo = reinterpret_cast<uintptr_t>(src);
-        const uintptr_t img_hi = img_lo + (size_t)(sh - 1) * pitch + (size_t)sw * CN;
-#pragma unroll 1
-        for (int r = 0; r < KS; r++) {
-            const int yy = iy + r;
-            if (yy < 0 || yy >= sh) continue;
-            const uintptr_t pa = img_lo + (uintptr_t)((long long)yy * (long long)pitch + (long long)ix * CN);
-            const uintptr_t b = pa & ~(uintptr_t)3;
-            uint32_t raw[NW + 1];
-            if (b >= img_lo && b + 4 * (NW + 1) <= img_hi) {
-#pragma unroll
-                for (int j = 0; j <= NW; j++) raw[j] = reinterpret_cast<const uint32_t*>(b)[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j <= NW; j++) {
-                    uint32_t v = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uintptr_t q = b + 4 * j + k;
-                        if (q >= img_lo && q < img_hi) v |= (uint32_t)*reinterpret_cast<const uint8_t*>(q) << (8 * k);
-                    }
-                    raw[j] = v;
-                }
-            }
-            mac_window_row<KS, CN, true>(raw, (uint32_t)(pa & 3), w + r * KS, acc, lo, hi);
+        for (int c = 0; c < CN; c++) {
+            const int b0 = (2 * q) * CN + c, j0 = b0 / 4, o0 = b0 % 4, o1 = o0 + CN;  // compile-time after unrolling
+            const uint32_t sel = 0x0c000c00u | (uint32_t)o0 | ((uint32_t)o1 << 16);
+            const uint32_t pr = __builtin_amdgcn_perm(win[j0 + 1], win[j0], sel);    // (tap 2q | tap 2q+1 << 16)
+            acc[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, pr), __builtin_bit_cast(s16x2_t, wq[q]),
+                                            acc[c], false);
         }
     }
-    store_rounded<CN>(acc, out);
 }
 
-// cv2.remap with CV_32FC1 maps.  What bounds the Lanczos case is not the arithmetic and not the source gather
-// but fetching each pixel's own 128-byte weight entry: eight 16-byte loads per lane, every one touching 64
-// different cache lines (measured: 4.0 ms per 64 1080p images, 1.6 ms with one shared entry).  So a wave fetches
-// its 64 entries cooperatively -- eight lanes per entry, one full line per eight lanes, 64 line look-ups instead
-// of 512 -- parks them in a wave-private LDS slab and every lane reads its own entry back with ds_read_b128.
-// The slab stride of 144 B keeps those reads conflict-free.
-template <int KS, int CN>
+// Variants of the interior path, measured on MI355X with tools/microtests/remap_bench.hip (64 1080p RGB images,
+// 16 images per workgroup; one image per workgroup: 2.95 ms):
+//   0             aligned dwords (x4 + x3 per row) + v_alignbyte, weights read from the LDS slab     2.14 ms
+//   bit 0  WIDE   the row fetched from its own byte address (no funnel shift)                         3.17 ms
+//                 -- byte-misaligned multi-dword global loads cost more than the shifts they save
+//   bit 1  WREG   the weight entry held in registers for all images                                   2.13 ms (116 VGPRs)
+//   bit 2  AHEAD  the rows of image z+1 requested before image z is reduced                           2.56 ms
+#ifndef CAMD_REMAP_VARIANT
+#define CAMD_REMAP_VARIANT 0
+#endif
+
+// One destination pixel of `nz` images that share a map (a batch of one rig): KS x KS taps at (ix, iy) ..
+// (ix+KS-1, iy+KS-1), weights w[KS*KS].  Everything that depends only on the map -- cell, phase, the weight
+// entry, the interior test, the byte offset of the window -- is worked out once and applied to every image.
+template <int KS, int CN, int VAR = CAMD_REMAP_VARIANT>
+__device__ __forceinline__ void gather_pixel_batch(const uint8_t* __restrict__ src, int sw, int sh, size_t pitch,
+                                                   size_t src_stride, int ix, int iy,
+                                                   const int16_t* __restrict__ w, uint8_t* out, size_t dst_stride,
+                                                   int nz)
+{
+    constexpr bool WIDE = VAR & 1, WREG = VAR & 2, AHEAD = VAR & 4;
+    constexpr int NB = KS * CN, NW = (NB + 3) / 4;
+    // pixels a row fetch may reach past the window: WIDE reads NW dwords from the window's own address, the aligned
+    // form up to 3 bytes before it and NW + 1 dwords
+    constexpr int OVER = WIDE ? (4 * NW - NB + CN - 1) / CN : (4 * (NW + 1) - NB + CN - 1) / CN;
+    constexpr int UNDER = WIDE ? 0 : (3 + CN - 1) / CN;
+    constexpr int NL = WIDE ? NW : NW + 1;  // dwords fetched per row
+    const bool interior = ix >= UNDER && iy >= 0 && ix + KS + OVER <= sw && iy + KS <= sh;
+    if (__all(interior)) {  // wave-uniform: a wave with any border lane takes the masked path below for all its lanes
+        uint32_t wreg[WREG ? KS * KS / 2 : 1];
+        if (WREG) {
+#pragma unroll
+            for (int i = 0; i < KS * KS / 2; i++) wreg[i] = reinterpret_cast<const uint32_t*>(w)[i];
+        }
+        const uintptr_t pa = reinterpret_cast<uintptr_t>(src + (size_t)iy * pitch + (size_t)ix * CN);
+        const uint32_t shb = (uint32_t)(pa & 3);
+        const uint8_t* p0 = reinterpret_cast<const uint8_t*>(WIDE ? pa : (pa & ~(uintptr_t)3));
+        uint32_t raw[AHEAD ? 2 : 1][KS][NL];
+        auto fetch = [&](int slot, const uint8_t* p) {
+#pragma unroll
+            for (int r = 0; r < KS; r++) __builtin_memcpy(raw[slot][r], p + (size_t)r * pitch, 4 * NL);
+        };
+        auto reduce = [&](int slot, uint8_t* o) {
+            int acc[CN];
+#pragma unroll
+            for (int c = 0; c < CN; c++) acc[c] = 0;
+#pragma unroll
+            for (int r = 0; r < KS; r++) {
+                uint32_t win[NW + 1];
+#pragma unroll
+                for (int j = 0; j < NW; j++)
+                    win[j] = WIDE ? raw[slot][r][j]
+                                  : __builtin_amdgcn_alignbyte(raw[slot][r][WIDE ? j : j + 1], raw[slot][r][j], shb);
+                win[NW] = 0;
+                uint32_t wrow[KS / 2];
+#pragma unroll
+                for (int q = 0; q < KS / 2; q++)
+                    wrow[q] = WREG ? wreg[r * (KS / 2) + q] : reinterpret_cast<const uint32_t*>(w)[r * (KS / 2) + q];
+                mac_row_regs<KS, CN>(win, wrow, acc);
+            }
+            store_rounded<CN>(acc, o);
+        };
+        if (AHEAD) {
+            fetch(0, p0);
+            int z = 0;
+            for (; z + 2 <= nz; z += 2) {  // two images per trip so that the slot index is static
+                fetch(1, p0 + (size_t)(z + 1) * src_stride);
+                reduce(0, out + (size_t)z * dst_stride);
+                if (z + 2 < nz) fetch(0, p0 + (size_t)(z + 2) * src_stride);
+                reduce(1, out + (size_t)(z + 1) * dst_stride);
+            }
+            if (z < nz) reduce(0, out + (size_t)z * dst_stride);
+        } else {
+#pragma unroll 1
+            for (int z = 0; z < nz; z++, p0 += src_stride, out += dst_stride) {
+                fetch(0, p0);
+                reduce(0, out);
+            }
+        }
+        return;
+    }
+    const bool touches = !(ix >= sw || ix + KS <= 0 || iy >= sh || iy + KS <= 0);
+    // The window crosses the image border (or sits too close to the end of a row for the over-read above).
+    // Same arithmetic: rows outside the image are skipped and the window bytes left or right of the row are masked
+    // to the constant border 0, so what the dword fetches pick up there (the neighbouring row) does not matter;
+    // only where they would leave the image buffer itself -- first row near x = 0, last row near x = sw -- are
+    // they replaced by guarded byte loads.
+    const int lo = max(0, -ix * CN), hi = min(KS * CN, (sw - ix) * CN);
+#pragma unroll 1
+    for (int z = 0; z < nz; z++, src += src_stride, out += dst_stride) {
+        int acc[CN];
+#pragma unroll
+        for (int c = 0; c < CN; c++) acc[c] = 0;
+        if (touches) {
+            const uintptr_t img_lo = reinterpret_cast<uintptr_t>(src);
+            const uintptr_t img_hi = img_lo + (size_t)(sh - 1) * pitch + (size_t)sw * CN;
+#pragma unroll 1
+            for (int r = 0; r < KS; r++) {
+                const int yy = iy + r;
+                if (yy < 0 || yy >= sh) continue;
+                const uintptr_t pa = img_lo + (uintptr_t)((long long)yy * (long long)pitch + (long long)ix * CN);
+                const uintptr_t b = pa & ~(uintptr_t)3;
+                uint32_t raw[NW + 1];
+                if (b >= img_lo && b + 4 * (NW + 1) <= img_hi) {
+#pragma unroll
+                    for (int j = 0; j <= NW; j++) raw[j] = reinterpret_cast<const uint32_t*>(b)[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j <= NW; j++) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uintptr_t q = b + 4 * j + k;
+                            if (q >= img_lo && q < img_hi) v |= (uint32_t)*reinterpret_cast<const uint8_t*>(q) << (8 * k);
+                        }
+                        raw[j] = v;
+                    }
+                }
+                mac_window_row<KS, CN, true>(raw, (uint32_t)(pa & 3), w + r * KS, acc, lo, hi);
+            }
+        }
+        store_rounded<CN>(acc, out);
+    }
+}
+
+// cv2.remap with CV_32FC1 maps; blockIdx.z owns `zb` consecutive images of the batch.  What bounds the Lanczos
+// case is not the arithmetic and not the source gather but fetching each pixel's own 128-byte weight entry: eight
+// 16-byte loads per lane, every one touching 64 different cache lines (measured: 4.0 ms per 64 1080p images, 1.6 ms
+// with one shared entry).  So a wave fetches its 64 entries cooperatively -- eight lanes per entry, one full line
+// per eight lanes, 64 line look-ups instead of 512 -- parks them in a wave-private LDS slab (stride 144 B:
+// conflict-free ds_read_b128) and every lane reads its own entry back; and since the images of a batch share the
+// rig's maps, map, phase and entry are fetched ONCE per destination pixel and applied to all `zb` images.
+template <int KS, int CN, int VAR = CAMD_REMAP_VARIANT>
 __global__ __launch_bounds__(256) void k_remap_f32(const uint8_t* __restrict__ src, int sw, int sh,
                                                    size_t src_pitch, size_t src_stride,
                                                    const float* __restrict__ mapx,
                                                    const float* __restrict__ mapy, uint8_t* __restrict__ dst,
                                                    int dw, int dh, size_t dst_pitch, size_t dst_stride,
-                                                   const int16_t* __restrict__ tab, int x_shift)
+                                                   const int16_t* __restrict__ tab, int x_shift, int batch, int zb)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, xm = x - x_shift;
+    const int z0 = blockIdx.z * zb, nz = min(zb, batch - z0);
     const bool act = x < dw && xm >= 0 && xm < dw;
     int a = 0, ix = 0, iy = 0;
     if (act) {
@@ -289,13 +374,16 @@ __global__ __launch_bounds__(256) void k_remap_f32(const uint8_t* __restrict__ s
         w = reinterpret_cast<const int16_t*>(slab + lane * SLAB_STRIDE);
     }
     if (x >= dw) return;
-    uint8_t* out = dst + (size_t)blockIdx.z * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN;
+    uint8_t* out = dst + (size_t)z0 * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN;
     if (!act) {
+        for (int z = 0; z < nz; z++, out += dst_stride) {
 #pragma unroll
-        for (int c = 0; c < CN; c++) out[c] = 0;
+            for (int c = 0; c < CN; c++) out[c] = 0;
+        }
         return;
     }
-    gather_pixel<KS, CN>(src + (size_t)blockIdx.z * src_stride, sw, sh, src_pitch, ix, iy, w, out);
+    gather_pixel_batch<KS, CN, VAR>(src + (size_t)z0 * src_stride, sw, sh, src_pitch, src_stride, ix, iy, w, out,
+                                    dst_stride, nz);
 }
 
 template <int CN>
@@ -331,16 +419,26 @@ __global__ __launch_bounds__(256) void k_remap_fixed_bilinear(const uint8_t* __r
                                                               const uint16_t* __restrict__ mapa,
                                                               uint8_t* __restrict__ dst, int dw, int dh,
                                                               size_t dst_pitch, size_t dst_stride,
-                                                              const int16_t* __restrict__ tab)
+                                                              const int16_t* __restrict__ tab, int batch, int zb)
 {
     int x = blockIdx.x * 256 + threadIdx.x;
     int y = blockIdx.y;
     if (x >= dw) return;
+    const int z0 = blockIdx.z * zb, nz = min(zb, batch - z0);
     size_t mi = (size_t)y * dw + x;
     int ix = mapxy[mi * 2], iy = mapxy[mi * 2 + 1];
     int a = mapa[mi] & (INTER_TAB_SIZE * INTER_TAB_SIZE - 1);
-    gather_pixel<2, CN>(src + (size_t)blockIdx.z * src_stride, sw, sh, src_pitch, ix, iy, tab + (size_t)a * 4,
-                        dst + (size_t)blockIdx.z * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN);
+    gather_pixel_batch<2, CN>(src + (size_t)z0 * src_stride, sw, sh, src_pitch, src_stride, ix, iy,
+                              tab + (size_t)a * 4,
+                              dst + (size_t)z0 * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN, dst_stride, nz);
+}
+
+// images per workgroup of the batch-inner kernels: all of them (up to 16) while the grid still fills the chip
+static int images_per_group(int groups_per_image, int batch)
+{
+    int zb = std::min(batch, 16);
+    while (zb > 1 && (long long)groups_per_image * div_up(batch, zb) < 4096) zb = (zb + 1) / 2;
+    return zb;
 }
 
 // host: one row of initUndistortRectifyMap's inner loop (X/Y/W accumulate per column, float64)
@@ -412,13 +510,15 @@ int camd_remap_u8(const uint8_t* src, int sw, int sh, int cn, size_t src_pitch, 
     if (rc != CAMD_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(div_up(dw, 256), dh, batch), block(256);
+    const int zb = images_per_group(grid.x * grid.y, batch);
+    const dim3 gridz(grid.x, grid.y, div_up(batch, zb));
 #define ARGS src, sw, sh, src_pitch, src_stride, mapx, mapy, dst, dw, dh, dst_pitch, dst_stride
     if (interp == CAMD_INTER_LANCZOS4) {
-        if (cn == 1) hipLaunchKernelGGL((k_remap_f32<8, 1>), grid, block, 0, st, ARGS, tl, x_shift);
-        else hipLaunchKernelGGL((k_remap_f32<8, 3>), grid, block, 0, st, ARGS, tl, x_shift);
+        if (cn == 1) hipLaunchKernelGGL((k_remap_f32<8, 1>), gridz, block, 0, st, ARGS, tl, x_shift, batch, zb);
+        else hipLaunchKernelGGL((k_remap_f32<8, 3>), gridz, block, 0, st, ARGS, tl, x_shift, batch, zb);
     } else if (interp == CAMD_INTER_LINEAR) {
-        if (cn == 1) hipLaunchKernelGGL((k_remap_f32<2, 1>), grid, block, 0, st, ARGS, tb, x_shift);
-        else hipLaunchKernelGGL((k_remap_f32<2, 3>), grid, block, 0, st, ARGS, tb, x_shift);
+        if (cn == 1) hipLaunchKernelGGL((k_remap_f32<2, 1>), gridz, block, 0, st, ARGS, tb, x_shift, batch, zb);
+        else hipLaunchKernelGGL((k_remap_f32<2, 3>), gridz, block, 0, st, ARGS, tb, x_shift, batch, zb);
     } else if (interp == CAMD_INTER_NEAREST) {
         if (cn == 1) hipLaunchKernelGGL((k_remap_nearest_u8<1>), grid, block, 0, st, ARGS, x_shift);
         else hipLaunchKernelGGL((k_remap_nearest_u8<3>), grid, block, 0, st, ARGS, x_shift);
@@ -446,13 +546,14 @@ int camd_remap_fixed_bilinear_u8(const uint8_t* src, int sw, int sh, int cn, siz
     rc = get_tables(&tl, &tb);
     if (rc != CAMD_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(div_up(dw, 256), dh, batch), block(256);
+    const int zb = images_per_group(div_up(dw, 256) * dh, batch);
+    dim3 grid(div_up(dw, 256), dh, div_up(batch, zb)), block(256);
     if (cn == 1)
         hipLaunchKernelGGL((k_remap_fixed_bilinear<1>), grid, block, 0, st, src, sw, sh, src_pitch, src_stride,
-                           mapxy, mapa, dst, dw, dh, dst_pitch, dst_stride, tb);
+                           mapxy, mapa, dst, dw, dh, dst_pitch, dst_stride, tb, batch, zb);
     else
         hipLaunchKernelGGL((k_remap_fixed_bilinear<3>), grid, block, 0, st, src, sw, sh, src_pitch, src_stride,
-                           mapxy, mapa, dst, dw, dh, dst_pitch, dst_stride, tb);
+                           mapxy, mapa, dst, dw, dh, dst_pitch, dst_stride, tb, batch, zb);
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
 }
