@@ -175,6 +175,9 @@ __device__ __forceinline__ void mac_window_row(const uint32_t (&raw)[(KS * CN + 
 template <int CN>
 __device__ __forceinline__ void store_rounded(const int (&acc)[CN], uint8_t* out)
 {
+#ifdef CAMD_REMAP_DBG_NOSTORE  // measurement only (tools/microtests/remap_bench.hip): keep the arithmetic, drop the stores
+    if (acc[0] != 0x12345678) return;
+#endif
 #pragma unroll
     for (int c = 0; c < CN; c++) {
         int v = (acc[c] + (1 << (COEF_BITS - 1))) >> COEF_BITS;
@@ -235,9 +238,11 @@ __device__ __forceinline__ void gather_pixel_batch(const uint8_t* __restrict__ s
 #pragma unroll
             for (int i = 0; i < KS * KS / 2; i++) wreg[i] = reinterpret_cast<const uint32_t*>(w)[i];
         }
-        const uintptr_t pa = reinterpret_cast<uintptr_t>(src + (size_t)iy * pitch + (size_t)ix * CN);
-        const uint32_t shb = (uint32_t)(pa & 3);
-        const uint8_t* p0 = reinterpret_cast<const uint8_t*>(WIDE ? pa : (pa & ~(uintptr_t)3));
+        // (the aligned base is reached by pointer arithmetic, not through an integer: the pointer then stays a global
+        // one and the row fetches are global_load, not flat_load)
+        const uint8_t* pw = src + (size_t)iy * pitch + (size_t)ix * CN;
+        const uint32_t shb = (uint32_t)(reinterpret_cast<uintptr_t>(pw) & 3);
+        const uint8_t* p0 = WIDE ? pw : pw - shb;
         uint32_t raw[AHEAD ? 2 : 1][KS][NL];
         auto fetch = [&](int slot, const uint8_t* p) {
 #pragma unroll
@@ -326,13 +331,19 @@ __device__ __forceinline__ void gather_pixel_batch(const uint8_t* __restrict__ s
     }
 }
 
-// cv2.remap with CV_32FC1 maps; blockIdx.z owns `zb` consecutive images of the batch.  What bounds the Lanczos
-// case is not the arithmetic and not the source gather but fetching each pixel's own 128-byte weight entry: eight
-// 16-byte loads per lane, every one touching 64 different cache lines (measured: 4.0 ms per 64 1080p images, 1.6 ms
-// with one shared entry).  So a wave fetches its 64 entries cooperatively -- eight lanes per entry, one full line
-// per eight lanes, 64 line look-ups instead of 512 -- parks them in a wave-private LDS slab (stride 144 B:
-// conflict-free ds_read_b128) and every lane reads its own entry back; and since the images of a batch share the
-// rig's maps, map, phase and entry are fetched ONCE per destination pixel and applied to all `zb` images.
+// Tried and measured slower (tools/microtests/remap_bench.hip, 64 1080p RGB images, 16 images per workgroup; the
+// gather above: 2.06 ms, 43 % of the VALU issue rate by SQ_INSTS_VALU, half of all wave cycles waiting on memory):
+// staging the wave's source box in LDS with coalesced dword loads through registers (2.16 ms at 168 VGPRs) or with
+// global_load_lds (3.5 ms: capped at 128 VGPRs the weight entry spills), requesting image z+1's rows before reducing
+// image z (2.56 ms; 7 ms when capped at 128 VGPRs), byte-exact row fetches without the funnel shift (3.17 ms).
+
+// cv2.remap with CV_32FC1 maps; blockIdx.z owns `zb` consecutive images of the batch.  What bounded the Lanczos
+// case first was fetching each pixel's own 128-byte weight entry: eight 16-byte loads per lane, every one touching
+// 64 different cache lines (measured: 4.0 ms per 64 1080p images, 1.6 ms with one shared entry).  So a wave fetches
+// its 64 entries cooperatively -- eight lanes per entry, one full line per eight lanes, 64 line look-ups instead of
+// 512 -- parks them in a wave-private LDS slab (stride 144 B: conflict-free ds_read_b128) and every lane reads its
+// own entry back; and since the images of a batch share the rig's maps, map, phase and entry are fetched ONCE per
+// destination pixel and applied to all `zb` images.
 template <int KS, int CN, int VAR = CAMD_REMAP_VARIANT>
 __global__ __launch_bounds__(256) void k_remap_f32(const uint8_t* __restrict__ src, int sw, int sh,
                                                    size_t src_pitch, size_t src_stride,
@@ -355,6 +366,7 @@ __global__ __launch_bounds__(256) void k_remap_f32(const uint8_t* __restrict__ s
         iy = min(max(sy >> INTER_BITS, -32768), 32767) - (KS / 2 - 1);
     }
     const int16_t* w = tab + (size_t)a * (KS * KS);
+    uint8_t* out = dst + (size_t)z0 * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN;
     if constexpr (KS == 8) {
         constexpr int SLAB_STRIDE = 144;  // bytes per entry in LDS: 128 + 16, so 16 lanes' b128 reads hit 64 distinct banks
         __shared__ __attribute__((aligned(16))) uint8_t s_w[4][64 * SLAB_STRIDE];
@@ -374,7 +386,6 @@ __global__ __launch_bounds__(256) void k_remap_f32(const uint8_t* __restrict__ s
         w = reinterpret_cast<const int16_t*>(slab + lane * SLAB_STRIDE);
     }
     if (x >= dw) return;
-    uint8_t* out = dst + (size_t)z0 * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN;
     if (!act) {
         for (int z = 0; z < nz; z++, out += dst_stride) {
 #pragma unroll

@@ -93,14 +93,18 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&Lp)[NR], uint32_t 
     uint32_t mn = SENT_PK;
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-        // C + min(Lp, Lp[d-1] + P1, Lp[d+1] + P1, delta) - delta  ==  C - max(delta - min(Lp, ...), 0)   (mod 2^16)
-        uint32_t t = pk_add_u16(pk_min_u16(m[k], m[k + 1]), P1pk);
-        uint32_t l = pk_sub_u16(c[k], pk_subsat_u16(delta, pk_min_u16(Lp[k], t)));
+        // C + min(Lp, Lp[d-1] + P1, Lp[d+1] + P1, delta) - delta  ==  C - max(delta - min(Lp, ...), 0)
+        // The + P1 and the final subtraction are plain 32-bit operations on the packed pair (v_add_u32 / v_sub_u32
+        // issue at twice the rate of the v_pk_* forms on gfx950, tools/microtests/valu_rate.hip): inside the int16
+        // regime no half can carry or borrow -- Lp <= 0x7fff and P1 < 0x8000, and L = C - (...) >= C - P2 >= 0
+        // because delta - min(...) <= P2 <= C.  (Outside it -- a flagged volume -- the result is discarded anyway.)
+        uint32_t t = pk_min_u16(m[k], m[k + 1]) + P1pk;
+        uint32_t l = c[k] - pk_subsat_u16(delta, pk_min_u16(Lp[k], t));
         if (PAD) l = (l & keep[k]) | sent[k];  // d >= D carries MAX_COST
         L[k] = l;
         mn = pk_min_u16(mn, l);
     }
-    return pk_add_u16(group_min_dup16<LANES>(mn), P2pk);
+    return group_min_dup16<LANES>(mn) + P2pk;  // (no carry: min <= 0x7fff, P2 < 0x8000)
 }
 
 
