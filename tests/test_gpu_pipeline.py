@@ -100,6 +100,47 @@ def test_remap_batched_tensor_input():
         assert np.array_equal(out[i].cpu().numpy(), imgproc.remap(src[i].cpu().numpy(), mapx, mapy))
 
 
+@pytest.mark.parametrize("cn", [1, 3])
+@pytest.mark.parametrize("n", [2, 17, 35])
+def test_batch_inner_kernels_against_the_oracle_per_image(oracle, cn, n):
+    """The images of a batch share the rig's maps: one workgroup applies a destination pixel's map, phase and weight
+    entry to up to 16 images (remap.hip / depth.hip).  Every image of a batch -- 17 and 35 leave ragged last groups --
+    must equal the oracle's result for that image alone: interior waves, waves crossing the border, the zero-filled
+    columns of an x-shift, distinct content per image."""
+    rng = np.random.default_rng(100 * cn + n)
+    sh, sw, dh, dw = 61, 333, 40, 300                      # 300 columns: a full 256-wide workgroup and a ragged one
+    src = rng.integers(0, 256, (n, sh, sw, cn), dtype=np.uint8)  # (a gray batch is (n, h, w, 1): 3-D means one (h, w, c) image)
+    one = (lambda a: a) if cn > 1 else (lambda a: a[..., 0])
+    mapx, mapy = _maps(rng, dh, dw, sw, sh, 1.5)           # mostly interior (the batch-inner fast path) ...
+    mapx[:, :20] -= 12.0                                   # ... with windows hanging over the left border,
+    mapy[-3:, :] += 9.0                                    # over the bottom border,
+    mapx[5, 100:110] = sw + 50.0                           # and entirely outside
+    d_src = torch.from_numpy(src).cuda()
+    d_mx, d_my = torch.from_numpy(mapx).cuda(), torch.from_numpy(mapy).cuda()
+    for interp, shift in ((imgproc.INTER_LANCZOS4, 0), (imgproc.INTER_LANCZOS4, 7), (imgproc.INTER_LINEAR, 0)):
+        got = imgproc.remap(d_src, d_mx, d_my, interp, x_shift=shift).cpu().numpy()
+        for i in range(n):
+            ref = oracle.remap_u8(one(src[i]), mapx, mapy, interp)
+            if shift:
+                ref = np.concatenate([np.zeros_like(ref[:, :shift]), ref[:, :-shift]], axis=1)
+            assert np.array_equal(one(got[i]), ref), (interp, shift, i)
+    # cv2.undistort's fixed-point bilinear remap, batched
+    rig = synthetic.rig(sw, sh)
+    K, D = np.array(rig["cam1"]["K"]), np.array(rig["cam1"]["D"])
+    mxy, ma = imgproc.undistort_maps(K, D, (sw, sh))
+    got = imgproc.remap_fixed_bilinear(d_src, torch.from_numpy(mxy).cuda(), torch.from_numpy(ma.view(np.int16)).cuda()).cpu().numpy()
+    for i in range(0, n, 5):
+        assert np.array_equal(one(got[i]), oracle.undistort_u8(one(src[i]), K, D)), i
+    # unrectify_depth, batched
+    depth = rng.uniform(0, 5, (n, sh, sw))
+    M = np.array([0.0123, -0.0045, 0.9991])
+    umx, umy = _maps(rng, dh, dw, sw, sh, 3.0)
+    got = imgproc.unrectify_depth(torch.from_numpy(depth).cuda(), M, torch.from_numpy(umx).cuda(),
+                                  torch.from_numpy(umy).cuda()).cpu().numpy()
+    for i in range(0, n, 4):
+        assert np.array_equal(got[i], oracle.unrectify_depth(depth[i], M, umx, umy)), i
+
+
 def test_undistort_bit_exact(oracle):
     rig = synthetic.rig(320, 240)
     K, D = np.array(rig["cam1"]["K"]), np.array(rig["cam1"]["D"])
