@@ -369,7 +369,11 @@ __global__ __launch_bounds__(256) void k_remap_f32(const uint8_t* __restrict__ s
     uint8_t* out = dst + (size_t)z0 * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN;
     if constexpr (KS == 8) {
         constexpr int SLAB_STRIDE = 144;  // bytes per entry in LDS: 128 + 16, so 16 lanes' b128 reads hit 64 distinct banks
+#ifdef CAMD_REMAP_DBG_EXTRA_LDS  // measurement only: fewer workgroups per CU (occupancy sensitivity)
+        __shared__ __attribute__((aligned(16))) uint8_t s_w[4][64 * SLAB_STRIDE + CAMD_REMAP_DBG_EXTRA_LDS];
+#else
         __shared__ __attribute__((aligned(16))) uint8_t s_w[4][64 * SLAB_STRIDE];
+#endif
         const int lane = threadIdx.x & 63;
         uint8_t* slab = s_w[threadIdx.x >> 6];
 #pragma unroll
