@@ -60,6 +60,11 @@ __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, a),
                                                                   __builtin_bit_cast(s16x2_t, b)));
 }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a),
+                                                                  __builtin_bit_cast(s16x2_t, b)));
+}
 // unsigned saturating subtract: max(a - b, 0) per half
 __device__ __forceinline__ uint32_t pk_subsat_u16(uint32_t a, uint32_t b)
 {

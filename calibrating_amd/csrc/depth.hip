@@ -12,27 +12,47 @@
 
 namespace camd {
 
+// a thread owns two consecutive pixels: the int16 pair arrives as one dword, the float and double pairs leave as
+// 8- and 16-byte stores
 __global__ __launch_bounds__(256) void k_disp_to_depth(const int16_t* __restrict__ disp16,
                                                        const uint8_t* __restrict__ mask, int n,
                                                        float thresh, float addv, int translate, float wf,
                                                        double bf, double max_depth,
                                                        float* __restrict__ disparity, double* __restrict__ depth)
 {
-    int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = 2 * (blockIdx.x * 256 + threadIdx.x);
     if (i >= n) return;
-    size_t o = (size_t)blockIdx.y * n + i;
-    float s = (float)disp16[o];
-    s = s < 0.f ? 0.f : s;
-    s = s < thresh ? 0.f : s;
-    float d = s / 16.0f;
-    d = __fdiv_rn(__fmul_rn(d, wf), wf);  // (d * w) / sw with sw == w, each op rounded like NumPy
-    if (translate) d = __fadd_rn(d, addv);
-    d = mask[i] ? d : __fmul_rn(0.f, d);
-    disparity[o] = d;
-    double z = __ddiv_rn(bf, (double)d);
-    z = z > max_depth ? 0. : z;
-    z = z < 0. ? 0. : z;
-    depth[o] = z;
+    const bool two = i + 1 < n;
+    const size_t o = (size_t)blockIdx.y * n + i;
+    uint32_t both;
+    if (two) __builtin_memcpy(&both, disp16 + o, 4);
+    else both = (uint16_t)disp16[o];
+    auto one = [&](int16_t raw, uint8_t m, float& dout, double& zout) {
+        float s = (float)raw;
+        s = s < 0.f ? 0.f : s;
+        s = s < thresh ? 0.f : s;
+        float d = s / 16.0f;
+        d = __fdiv_rn(__fmul_rn(d, wf), wf);  // (d * w) / sw with sw == w, each op rounded like NumPy
+        if (translate) d = __fadd_rn(d, addv);
+        d = m ? d : __fmul_rn(0.f, d);
+        dout = d;
+        double z = __ddiv_rn(bf, (double)d);
+        z = z > max_depth ? 0. : z;
+        zout = z < 0. ? 0. : z;
+    };
+    float d0, d1 = 0.f;
+    double z0, z1 = 0.;
+    one((int16_t)(both & 0xffffu), mask[i], d0, z0);
+    if (two) {
+        one((int16_t)(both >> 16), mask[i + 1], d1, z1);
+        const float dd[2] = {d0, d1};
+        const double zz[2] = {z0, z1};
+        __builtin_memcpy(disparity + o, dd, 8);
+        __builtin_memcpy(depth + o, zz, 16);
+    } else {
+        disparity[o] = d0;
+        depth[o] = z0;
+    }
 }
 
 // The images of a batch share the rig's maps: blockIdx.z owns `zb` consecutive images, so the map pair, the rounding
@@ -85,7 +105,7 @@ int camd_disp_to_depth(const int16_t* disp16, const uint8_t* valid_mask, int w, 
     int rc = camd_device_ok();
     if (rc != CAMD_OK) return rc;
     int n = w * h;
-    hipLaunchKernelGGL(k_disp_to_depth, dim3(div_up(n, 256), batch), dim3(256), 0, (hipStream_t)stream, disp16,
+    hipLaunchKernelGGL(k_disp_to_depth, dim3(div_up(div_up(n, 2), 256), batch), dim3(256), 0, (hipStream_t)stream, disp16,
                        valid_mask, n, (float)(sgbm_min_disparity * 16), (float)add_min_disparity, translate,
                        (float)w, baseline_fx, max_depth, disparity, depth);
     CAMD_LAUNCH_CHECK();

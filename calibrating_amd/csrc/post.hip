@@ -11,40 +11,54 @@
 
 namespace camd {
 
-__device__ __forceinline__ void sort2(int& a, int& b)
+// exchange on two pixels at once: the signed 16-bit halves of a and b sorted independently
+__device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b)
 {
-    int t = min(a, b);
-    b = max(a, b);
+    const uint32_t t = pk_min_i16(a, b);
+    b = pk_max_i16(a, b);
     a = t;
 }
 
+// A thread owns the pixel pair (2i, 2i+1) of a row: its own pair arrives as one dword (global loads take any byte
+// address on gfx950), the neighbour to the left and to the right as shorts, and the 19-exchange median network runs on
+// packed int16 pairs (v_pk_min_i16 / v_pk_max_i16): half the loads and half the exchanges per pixel.
 __global__ __launch_bounds__(256) void k_median3(const int16_t* __restrict__ src, size_t sp, size_t ss,
                                                  int16_t* __restrict__ dst, size_t dp, size_t ds, int w, int h)
 {
-    int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
+    const int x = 2 * (blockIdx.x * 256 + threadIdx.x);
+    const int y = blockIdx.y;
     if (x >= w) return;
+    const bool two = x + 1 < w;  // (the last pair of an odd-width row holds one pixel)
     const int16_t* s = src + (size_t)blockIdx.z * ss;
-    int x0 = x > 0 ? x - 1 : x, x2 = x < w - 1 ? x + 1 : x;
-    const int16_t* r0 = s + (size_t)(y > 0 ? y - 1 : y) * sp;
-    const int16_t* r1 = s + (size_t)y * sp;
-    const int16_t* r2 = s + (size_t)(y < h - 1 ? y + 1 : y) * sp;
-    int p0 = r0[x0], p1 = r0[x], p2 = r0[x2];
-    int p3 = r1[x0], p4 = r1[x], p5 = r1[x2];
-    int p6 = r2[x0], p7 = r2[x], p8 = r2[x2];
+    const int xl = x > 0 ? x - 1 : 0, xr = min(x + 2, w - 1);
+    const int16_t* rows[3] = {s + (size_t)(y > 0 ? y - 1 : y) * sp, s + (size_t)y * sp,
+                              s + (size_t)(y < h - 1 ? y + 1 : y) * sp};
+    uint32_t p[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        uint32_t own;
+        if (two) __builtin_memcpy(&own, rows[r] + x, 4);
+        else own = dup16((uint16_t)rows[r][x]);  // replicate border: the missing right neighbour is the pixel itself
+        const uint32_t l = (uint16_t)rows[r][xl], rr = (uint16_t)rows[r][xr];
+        p[3 * r + 0] = l | (own << 16);           // left neighbours of (x, x+1):   (x-1, x)
+        p[3 * r + 1] = own;                       //                                 (x,   x+1)
+        p[3 * r + 2] = (own >> 16) | (rr << 16);  // right neighbours:              (x+1, x+2)
+    }
     // median of 9 by the classic 19-exchange network
-    sort2(p1, p2); sort2(p4, p5); sort2(p7, p8); sort2(p0, p1);
-    sort2(p3, p4); sort2(p6, p7); sort2(p1, p2); sort2(p4, p5);
-    sort2(p7, p8); sort2(p0, p3); sort2(p5, p8); sort2(p4, p7);
-    sort2(p3, p6); sort2(p1, p4); sort2(p2, p5); sort2(p4, p7);
-    sort2(p4, p2); sort2(p6, p4); sort2(p4, p2);
-    dst[(size_t)blockIdx.z * ds + (size_t)y * dp + x] = (int16_t)p4;
+    sort2(p[1], p[2]); sort2(p[4], p[5]); sort2(p[7], p[8]); sort2(p[0], p[1]);
+    sort2(p[3], p[4]); sort2(p[6], p[7]); sort2(p[1], p[2]); sort2(p[4], p[5]);
+    sort2(p[7], p[8]); sort2(p[0], p[3]); sort2(p[5], p[8]); sort2(p[4], p[7]);
+    sort2(p[3], p[6]); sort2(p[1], p[4]); sort2(p[2], p[5]); sort2(p[4], p[7]);
+    sort2(p[4], p[2]); sort2(p[6], p[4]); sort2(p[4], p[2]);
+    int16_t* o = dst + (size_t)blockIdx.z * ds + (size_t)y * dp + x;
+    if (two) __builtin_memcpy(o, &p[4], 4);
+    else *o = (int16_t)(p[4] & 0xffffu);
 }
 
 int launch_median3(const int16_t* src, size_t sp, size_t ss, int16_t* dst, size_t dp, size_t ds, int w, int h,
                    int batch, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_median3, dim3(div_up(w, 256), h, batch), dim3(256), 0, st, src, sp, ss, dst, dp, ds,
+    hipLaunchKernelGGL(k_median3, dim3(div_up(div_up(w, 2), 256), h, batch), dim3(256), 0, st, src, sp, ss, dst, dp, ds,
                        w, h);
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
