@@ -623,12 +623,15 @@ def main():
             hit = [v["hbm_bytes_per_pair"] for k, v in pmc["kernels"].items() if all(s in k for s in keys)]
             return hit[0] if len(hit) == 1 else None
 
-        def valu_insts_per_pair(keys):
-            """SQ_INSTS_VALU (wave-instructions) per pair from the committed SQ counter profile of the same kernel."""
+        def sq_counters(keys):
+            """(SQ_INSTS_VALU wave-instructions per pair, fraction of wave cycles spent in s_waitcnt / s_barrier) from the
+            committed SQ counter profile of the same kernel."""
             if not sq:
-                return None
-            hit = [v.get("SQ_INSTS_VALU") for k, v in sq["kernels"].items() if all(s_ in k for s_ in keys)]
-            return hit[0] / sq["pairs_per_launch"] if len(hit) == 1 and hit[0] else None
+                return None, None
+            hit = [v for k, v in sq["kernels"].items() if all(s_ in k for s_ in keys)]
+            if len(hit) != 1 or not hit[0].get("SQ_INSTS_VALU"):
+                return None, None
+            return hit[0]["SQ_INSTS_VALU"] / sq["pairs_per_launch"], hit[0].get("derived", {}).get("wait_any_frac")
 
         kernels = {}
         for st, ms_sum in stage_ms.items():
@@ -641,13 +644,16 @@ def main():
             kernels[st] = {"kernel": name, "avg_ms_per_launch": ms, "algorithmic_bytes_per_launch": float(per_pair * nb),
                            "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": (tr * nb) if tr is not None else None}
-            vi = valu_insts_per_pair(keys)
+            vi, waitf = sq_counters(keys)
             if vi is not None:
-                # VALU issue roofline: one wave-instruction per CU and cycle; the instruction count is a property of
-                # the kernel (counted once, committed), the duration is this run's
+                # VALU issue roofline: one (packed-form) wave-instruction per CU and cycle; the instruction count is a
+                # property of the kernel (counted once, committed), the duration is this run's.  A kernel that reaches
+                # neither 0.8 of that nor 0.6 of the HBM peak is bound by its dependency chain (barrier per step, waits):
+                # `wave_wait_frac` = share of wave cycles in s_waitcnt / s_barrier
                 vf = vi * nb / (N_CUS * CLOCK_HZ) / (ms * 1e-3)
-                kernels[st].update(valu_wave_insts_per_launch=vi * nb, valu_frac=vf,
-                                   bound="valu" if vf >= max(0.5, ach / HBM_PEAK_GBS) else "hbm")
+                hf = ach / HBM_PEAK_GBS
+                kernels[st].update(valu_wave_insts_per_launch=vi * nb, valu_frac=vf, wave_wait_frac=waitf,
+                                   bound="valu" if vf >= 0.8 else "hbm" if hf >= 0.6 else "latency")
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms_per_launch"]) if kernels else None
         # whole-step traffic = every kernel of the committed PMC profile (incl. the small init / check kernels)
         traffic_total = sum(v["hbm_bytes_per_pair"] for v in pmc["kernels"].values()) * nb if pmc else None

@@ -136,9 +136,11 @@ __global__ __launch_bounds__(256) void k_cc_rows(const int16_t* __restrict__ img
     if (lane == 0) p.cl = false;  // the link to the previous wave is an explicit union in k_cc_merge
     const unsigned long long m = __ballot(p.cl);
     if (x < w) {
-        const int i = y * w + x;
-        parent[i] = i - (lane - cc_run_start(m, lane));
-        parent[w * h + i] = 0;  // count
+        const int i = y * w + x, start = cc_run_start(m, lane);
+        parent[i] = i - (lane - start);
+        // counts live at roots, and a root is always the first pixel of a run-in-the-wave (unions hook the larger
+        // root under the smaller, so roots stay among the initial ones): only those are zeroed
+        if (start == lane) parent[w * h + i] = 0;
     }
 }
 
@@ -190,22 +192,28 @@ __global__ __launch_bounds__(256) void k_cc_count(const int16_t* __restrict__ im
     atomicAdd(&count[r], len);
 }
 
+// one walk to the root per run-in-the-wave: its first pixel looks the component's size up, the others take its verdict
 __global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, size_t stride,
                                                   const int* __restrict__ parent, int w, int h, int new_val,
-                                                  int max_size)
+                                                  int max_size, int max_diff)
 {
-    int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
-    if (x >= w) return;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
     img += (size_t)blockIdx.z * stride;
     parent += (size_t)blockIdx.z * 2 * w * h;
     const int* count = parent + w * h;
-    int16_t* p = img + (size_t)y * pitch + x;
-    if (*p == new_val) return;
-    // pixel -> first pixel of its run -> (compressed by k_cc_count) root; walk read-only
-    int r = y * w + x;
-    for (int q = parent[r]; q != r; q = parent[r]) r = q;
-    if (count[r] <= max_size) *p = (int16_t)new_val;
+    CcPix p = cc_load(img + (size_t)y * pitch, x, w, new_val, max_diff);
+    if (lane == 0) p.cl = false;
+    const unsigned long long m = __ballot(p.cl);
+    const int start = cc_run_start(m, lane);
+    int kill = 0;
+    if (x < w && p.valid && start == lane) {
+        // first pixel of its run -> (compressed by k_cc_count) root; walk read-only
+        int r = y * w + x;
+        for (int q = parent[r]; q != r; q = parent[r]) r = q;
+        kill = count[r] <= max_size;
+    }
+    kill = __shfl(kill, start);
+    if (x < w && p.valid && kill) img[(size_t)y * pitch + x] = (int16_t)new_val;
 }
 
 size_t speckle_ws_bytes(int w, int h, int batch)
@@ -225,7 +233,8 @@ int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, 
     hipLaunchKernelGGL(k_cc_rows, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
     hipLaunchKernelGGL(k_cc_merge, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
     hipLaunchKernelGGL(k_cc_count, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
-    hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_size);
+    hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_size,
+                       max_diff);
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
 }
