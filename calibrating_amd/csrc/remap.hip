@@ -204,95 +204,55 @@ __device__ __forceinline__ void mac_row_regs(const uint32_t (&win)[(KS * CN + 3)
     }
 }
 
-// Variants of the interior path, measured on MI355X with tools/microtests/remap_bench.hip (64 1080p RGB images,
-// 16 images per workgroup; one image per workgroup: 2.95 ms):
-//   0             aligned dwords (x4 + x3 per row) + v_alignbyte, weights read from the LDS slab     2.14 ms
-//   bit 0  WIDE   the row fetched from its own byte address (no funnel shift)                         3.17 ms
-//                 -- byte-misaligned multi-dword global loads cost more than the shifts they save
-//   bit 1  WREG   the weight entry held in registers for all images                                   2.13 ms (116 VGPRs)
-//   bit 2  AHEAD  the rows of image z+1 requested before image z is reduced                           2.56 ms
-#ifndef CAMD_REMAP_VARIANT
-#define CAMD_REMAP_VARIANT 0
-#endif
-
 // One destination pixel of `nz` images that share a map (a batch of one rig): KS x KS taps at (ix, iy) ..
-// (ix+KS-1, iy+KS-1), weights w[KS*KS].  Everything that depends only on the map -- cell, phase, the weight
-// entry, the interior test, the byte offset of the window -- is worked out once and applied to every image.
-template <int KS, int CN, int VAR = CAMD_REMAP_VARIANT>
+// (ix+KS-1, iy+KS-1).  Everything that depends only on the map -- cell, phase, the weight entry (in registers:
+// wreg), the interior test, the byte offset of the window -- is worked out once and applied to every image.
+// A window row is fetched as aligned dwords (x4 + x3) and funnel-shifted into place; HR rows are requested at a time
+// (KS / 2 for Lanczos: with the entry in registers and half the rows in flight the kernel needs 80 VGPRs and no LDS
+// while it walks the images, so six waves per SIMD cover the gather's latency).
+// Measured on 64 1080p RGB images, 16 images per workgroup (tools/microtests/remap_bench.hip; one image per workgroup
+// and the entry behind an LDS slab, round 2's form: 2.95 ms): entry in LDS / registers at 117 VGPRs and 4 waves per
+// SIMD 2.06 ms; registers, all 8 rows at once (97 VGPRs) 1.63; 4 rows at a time, 6 waves per SIMD 1.48; 2 rows at a
+// time, 7 waves 1.68.  Slower and dropped: byte-exact misaligned row fetches 3.17, prefetching the next image's rows
+// 2.56 (7 ms when capped at 128 VGPRs), staging the source box in LDS through registers 2.16 or by global_load_lds 3.5.
+template <int KS, int CN, int HR>
 __device__ __forceinline__ void gather_pixel_batch(const uint8_t* __restrict__ src, int sw, int sh, size_t pitch,
                                                    size_t src_stride, int ix, int iy,
-                                                   const int16_t* __restrict__ w, uint8_t* out, size_t dst_stride,
+                                                   const uint32_t (&wreg)[KS * KS / 2], uint8_t* out, size_t dst_stride,
                                                    int nz)
 {
-    constexpr bool WIDE = VAR & 1, WREG = VAR & 2, AHEAD = VAR & 4;
-    constexpr int NB = KS * CN, NW = (NB + 3) / 4;
-    // pixels a row fetch may reach past the window: WIDE reads NW dwords from the window's own address, the aligned
-    // form up to 3 bytes before it and NW + 1 dwords
-    constexpr int OVER = WIDE ? (4 * NW - NB + CN - 1) / CN : (4 * (NW + 1) - NB + CN - 1) / CN;
-    constexpr int UNDER = WIDE ? 0 : (3 + CN - 1) / CN;
-    constexpr int NL = WIDE ? NW : NW + 1;  // dwords fetched per row
+    constexpr int NB = KS * CN, NW = (NB + 3) / 4, NL = NW + 1;
+    constexpr int OVER = (4 * (NW + 1) - NB + CN - 1) / CN, UNDER = (3 + CN - 1) / CN;
     const bool interior = ix >= UNDER && iy >= 0 && ix + KS + OVER <= sw && iy + KS <= sh;
-    if (__all(interior)) {  // wave-uniform: a wave with any border lane takes the masked path below for all its lanes
-        uint32_t wreg[WREG ? KS * KS / 2 : 1];
-        if (WREG) {
-#pragma unroll
-            for (int i = 0; i < KS * KS / 2; i++) wreg[i] = reinterpret_cast<const uint32_t*>(w)[i];
-        }
-        // (the aligned base is reached by pointer arithmetic, not through an integer: the pointer then stays a global
-        // one and the row fetches are global_load, not flat_load)
+    if (__all(interior)) {
         const uint8_t* pw = src + (size_t)iy * pitch + (size_t)ix * CN;
         const uint32_t shb = (uint32_t)(reinterpret_cast<uintptr_t>(pw) & 3);
-        const uint8_t* p0 = WIDE ? pw : pw - shb;
-        uint32_t raw[AHEAD ? 2 : 1][KS][NL];
-        auto fetch = [&](int slot, const uint8_t* p) {
-#pragma unroll
-            for (int r = 0; r < KS; r++) __builtin_memcpy(raw[slot][r], p + (size_t)r * pitch, 4 * NL);
-        };
-        auto reduce = [&](int slot, uint8_t* o) {
+        const uint8_t* p0 = pw - shb;
+        uint32_t raw[HR][NL];
+#pragma unroll 1
+        for (int z = 0; z < nz; z++, p0 += src_stride, out += dst_stride) {
             int acc[CN];
 #pragma unroll
             for (int c = 0; c < CN; c++) acc[c] = 0;
 #pragma unroll
-            for (int r = 0; r < KS; r++) {
-                uint32_t win[NW + 1];
+            for (int r0 = 0; r0 < KS; r0 += HR) {
 #pragma unroll
-                for (int j = 0; j < NW; j++)
-                    win[j] = WIDE ? raw[slot][r][j]
-                                  : __builtin_amdgcn_alignbyte(raw[slot][r][WIDE ? j : j + 1], raw[slot][r][j], shb);
-                win[NW] = 0;
-                uint32_t wrow[KS / 2];
+                for (int r = 0; r < HR; r++) __builtin_memcpy(raw[r], p0 + (size_t)(r0 + r) * pitch, 4 * NL);
 #pragma unroll
-                for (int q = 0; q < KS / 2; q++)
-                    wrow[q] = WREG ? wreg[r * (KS / 2) + q] : reinterpret_cast<const uint32_t*>(w)[r * (KS / 2) + q];
-                mac_row_regs<KS, CN>(win, wrow, acc);
+                for (int r = 0; r < HR; r++) {
+                    uint32_t win[NW + 1];
+#pragma unroll
+                    for (int j = 0; j < NW; j++) win[j] = __builtin_amdgcn_alignbyte(raw[r][j + 1], raw[r][j], shb);
+                    win[NW] = 0;
+                    mac_row_regs<KS, CN>(win, wreg + (r0 + r) * (KS / 2), acc);
+                }
+                if (HR < KS) __builtin_amdgcn_sched_barrier(0);  // keep the next portion's loads behind this portion's use
             }
-            store_rounded<CN>(acc, o);
-        };
-        if (AHEAD) {
-            fetch(0, p0);
-            int z = 0;
-            for (; z + 2 <= nz; z += 2) {  // two images per trip so that the slot index is static
-                fetch(1, p0 + (size_t)(z + 1) * src_stride);
-                reduce(0, out + (size_t)z * dst_stride);
-                if (z + 2 < nz) fetch(0, p0 + (size_t)(z + 2) * src_stride);
-                reduce(1, out + (size_t)(z + 1) * dst_stride);
-            }
-            if (z < nz) reduce(0, out + (size_t)z * dst_stride);
-        } else {
-#pragma unroll 1
-            for (int z = 0; z < nz; z++, p0 += src_stride, out += dst_stride) {
-                fetch(0, p0);
-                reduce(0, out);
-            }
+            store_rounded<CN>(acc, out);
         }
         return;
     }
     const bool touches = !(ix >= sw || ix + KS <= 0 || iy >= sh || iy + KS <= 0);
-    // The window crosses the image border (or sits too close to the end of a row for the over-read above).
-    // Same arithmetic: rows outside the image are skipped and the window bytes left or right of the row are masked
-    // to the constant border 0, so what the dword fetches pick up there (the neighbouring row) does not matter;
-    // only where they would leave the image buffer itself -- first row near x = 0, last row near x = sw -- are
-    // they replaced by guarded byte loads.
     const int lo = max(0, -ix * CN), hi = min(KS * CN, (sw - ix) * CN);
 #pragma unroll 1
     for (int z = 0; z < nz; z++, src += src_stride, out += dst_stride) {
@@ -302,16 +262,16 @@ __device__ __forceinline__ void gather_pixel_batch(const uint8_t* __restrict__ s
         if (touches) {
             const uintptr_t img_lo = reinterpret_cast<uintptr_t>(src);
             const uintptr_t img_hi = img_lo + (size_t)(sh - 1) * pitch + (size_t)sw * CN;
-#pragma unroll 1
-            for (int r = 0; r < KS; r++) {
+#pragma unroll
+            for (int r = 0; r < KS; r++) {  // (unrolled: the weights are registers, their index must be static)
                 const int yy = iy + r;
                 if (yy < 0 || yy >= sh) continue;
                 const uintptr_t pa = img_lo + (uintptr_t)((long long)yy * (long long)pitch + (long long)ix * CN);
                 const uintptr_t b = pa & ~(uintptr_t)3;
-                uint32_t raw[NW + 1];
+                uint32_t rw[NW + 1];
                 if (b >= img_lo && b + 4 * (NW + 1) <= img_hi) {
 #pragma unroll
-                    for (int j = 0; j <= NW; j++) raw[j] = reinterpret_cast<const uint32_t*>(b)[j];
+                    for (int j = 0; j <= NW; j++) rw[j] = reinterpret_cast<const uint32_t*>(b)[j];
                 } else {
 #pragma unroll
                     for (int j = 0; j <= NW; j++) {
@@ -321,36 +281,31 @@ __device__ __forceinline__ void gather_pixel_batch(const uint8_t* __restrict__ s
                             const uintptr_t q = b + 4 * j + k;
                             if (q >= img_lo && q < img_hi) v |= (uint32_t)*reinterpret_cast<const uint8_t*>(q) << (8 * k);
                         }
-                        raw[j] = v;
+                        rw[j] = v;
                     }
                 }
-                mac_window_row<KS, CN, true>(raw, (uint32_t)(pa & 3), w + r * KS, acc, lo, hi);
+                mac_window_row<KS, CN, true>(rw, (uint32_t)(pa & 3), reinterpret_cast<const int16_t*>(wreg + r * (KS / 2)), acc,
+                                             lo, hi);
             }
         }
         store_rounded<CN>(acc, out);
     }
 }
 
-// Tried and measured slower (tools/microtests/remap_bench.hip, 64 1080p RGB images, 16 images per workgroup; the
-// gather above: 2.06 ms, 43 % of the VALU issue rate by SQ_INSTS_VALU, half of all wave cycles waiting on memory):
-// staging the wave's source box in LDS with coalesced dword loads through registers (2.16 ms at 168 VGPRs) or with
-// global_load_lds (3.5 ms: capped at 128 VGPRs the weight entry spills), requesting image z+1's rows before reducing
-// image z (2.56 ms; 7 ms when capped at 128 VGPRs), byte-exact row fetches without the funnel shift (3.17 ms).
-
 // cv2.remap with CV_32FC1 maps; blockIdx.z owns `zb` consecutive images of the batch.  What bounded the Lanczos
 // case first was fetching each pixel's own 128-byte weight entry: eight 16-byte loads per lane, every one touching
-// 64 different cache lines (measured: 4.0 ms per 64 1080p images, 1.6 ms with one shared entry).  So a wave fetches
-// its 64 entries cooperatively -- eight lanes per entry, one full line per eight lanes, 64 line look-ups instead of
-// 512 -- parks them in a wave-private LDS slab (stride 144 B: conflict-free ds_read_b128) and every lane reads its
-// own entry back; and since the images of a batch share the rig's maps, map, phase and entry are fetched ONCE per
-// destination pixel and applied to all `zb` images.
-template <int KS, int CN, int VAR = CAMD_REMAP_VARIANT>
-__global__ __launch_bounds__(256) void k_remap_f32(const uint8_t* __restrict__ src, int sw, int sh,
-                                                   size_t src_pitch, size_t src_stride,
-                                                   const float* __restrict__ mapx,
-                                                   const float* __restrict__ mapy, uint8_t* __restrict__ dst,
-                                                   int dw, int dh, size_t dst_pitch, size_t dst_stride,
-                                                   const int16_t* __restrict__ tab, int x_shift, int batch, int zb)
+// 64 different cache lines.  So a wave fetches its 64 entries cooperatively into a wave-private LDS slab and every
+// lane reads its own entry back -- in two halves of 64 bytes (four lanes per half entry: 64 contiguous bytes; slab
+// stride 80 B: conflict-free ds_read_b128), 5 KB of LDS per wave, none of it needed once the entry is in registers.
+#ifndef CAMD_REMAP_ROWS_PER_FETCH
+#define CAMD_REMAP_ROWS_PER_FETCH 4
+#endif
+template <int KS, int CN, int HR = (KS == 8 ? CAMD_REMAP_ROWS_PER_FETCH : KS)>
+__global__ __launch_bounds__(256, KS != 8 ? 1 : HR == 8 ? 4 : HR == 4 ? 6 : 7)
+void k_remap_f32(const uint8_t* __restrict__ src, int sw, int sh, size_t src_pitch, size_t src_stride,
+                 const float* __restrict__ mapx, const float* __restrict__ mapy, uint8_t* __restrict__ dst, int dw,
+                 int dh, size_t dst_pitch, size_t dst_stride, const int16_t* __restrict__ tab, int x_shift, int batch,
+                 int zb)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, xm = x - x_shift;
     const int z0 = blockIdx.z * zb, nz = min(zb, batch - z0);
@@ -365,40 +320,51 @@ __global__ __launch_bounds__(256) void k_remap_f32(const uint8_t* __restrict__ s
         ix = min(max(sx >> INTER_BITS, -32768), 32767) - (KS / 2 - 1);
         iy = min(max(sy >> INTER_BITS, -32768), 32767) - (KS / 2 - 1);
     }
-    const int16_t* w = tab + (size_t)a * (KS * KS);
-    uint8_t* out = dst + (size_t)z0 * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN;
+    uint32_t wreg[KS * KS / 2];
     if constexpr (KS == 8) {
-        constexpr int SLAB_STRIDE = 144;  // bytes per entry in LDS: 128 + 16, so 16 lanes' b128 reads hit 64 distinct banks
-#ifdef CAMD_REMAP_DBG_EXTRA_LDS  // measurement only: fewer workgroups per CU (occupancy sensitivity)
-        __shared__ __attribute__((aligned(16))) uint8_t s_w[4][64 * SLAB_STRIDE + CAMD_REMAP_DBG_EXTRA_LDS];
-#else
-        __shared__ __attribute__((aligned(16))) uint8_t s_w[4][64 * SLAB_STRIDE];
-#endif
+        constexpr int HS = 80;
+        __shared__ __attribute__((aligned(16))) uint8_t s_h[4][64 * HS];
         const int lane = threadIdx.x & 63;
-        uint8_t* slab = s_w[threadIdx.x >> 6];
+        uint8_t* slab = s_h[threadIdx.x >> 6];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int e = i * 8 + (lane >> 3);  // the lane whose entry this group of eight lanes fetches
-            const int ae = __shfl(a, e);
-            const uint4 v = *reinterpret_cast<const uint4*>(tab + (size_t)ae * 64 + (lane & 7) * 8);
-            *reinterpret_cast<uint4*>(slab + e * SLAB_STRIDE + (lane & 7) * 16) = v;
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = i * 16 + (lane >> 2);  // the lane whose half entry this group of four lanes fetches
+                const int ae = __shfl(a, e);
+                const uint4 v = *reinterpret_cast<const uint4*>(tab + (size_t)ae * 64 + half * 32 + (lane & 3) * 8);
+                *reinterpret_cast<uint4*>(slab + e * HS + (lane & 3) * 16) = v;
+            }
+            // the slab is private to this wave and LDS executes a wave's operations in order: only the compiler
+            // has to be kept from moving the reads above the writes (and the next half's writes above the reads)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = *reinterpret_cast<const uint4*>(slab + lane * HS + q * 16);
+                wreg[half * 16 + 4 * q] = v.x;
+                wreg[half * 16 + 4 * q + 1] = v.y;
+                wreg[half * 16 + 4 * q + 2] = v.z;
+                wreg[half * 16 + 4 * q + 3] = v.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        // the slab is private to this wave and LDS executes a wave's operations in order: only the compiler
-        // has to be kept from moving the reads above the writes
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        w = reinterpret_cast<const int16_t*>(slab + lane * SLAB_STRIDE);
+    } else {
+#pragma unroll
+        for (int i = 0; i < KS * KS / 2; i++) wreg[i] = reinterpret_cast<const uint32_t*>(tab + (size_t)a * (KS * KS))[i];
     }
     if (x >= dw) return;
-    if (!act) {
+    uint8_t* out = dst + (size_t)z0 * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN;
+    if (!act) {  // the columns the x-shift leaves empty
         for (int z = 0; z < nz; z++, out += dst_stride) {
 #pragma unroll
             for (int c = 0; c < CN; c++) out[c] = 0;
         }
         return;
     }
-    gather_pixel_batch<KS, CN, VAR>(src + (size_t)z0 * src_stride, sw, sh, src_pitch, src_stride, ix, iy, w, out,
-                                    dst_stride, nz);
+    gather_pixel_batch<KS, CN, HR>(src + (size_t)z0 * src_stride, sw, sh, src_pitch, src_stride, ix, iy, wreg, out,
+                                   dst_stride, nz);
 }
 
 template <int CN>
@@ -443,9 +409,10 @@ __global__ __launch_bounds__(256) void k_remap_fixed_bilinear(const uint8_t* __r
     size_t mi = (size_t)y * dw + x;
     int ix = mapxy[mi * 2], iy = mapxy[mi * 2 + 1];
     int a = mapa[mi] & (INTER_TAB_SIZE * INTER_TAB_SIZE - 1);
-    gather_pixel_batch<2, CN>(src + (size_t)z0 * src_stride, sw, sh, src_pitch, src_stride, ix, iy,
-                              tab + (size_t)a * 4,
-                              dst + (size_t)z0 * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN, dst_stride, nz);
+    const uint32_t* e = reinterpret_cast<const uint32_t*>(tab + (size_t)a * 4);
+    const uint32_t wreg[2] = {e[0], e[1]};
+    gather_pixel_batch<2, CN, 2>(src + (size_t)z0 * src_stride, sw, sh, src_pitch, src_stride, ix, iy, wreg,
+                                 dst + (size_t)z0 * dst_stride + (size_t)y * dst_pitch + (size_t)x * CN, dst_stride, nz);
 }
 
 // images per workgroup of the batch-inner kernels: all of them (up to 16) while the grid still fills the chip

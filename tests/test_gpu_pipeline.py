@@ -185,6 +185,19 @@ def test_disp_to_depth_and_unrectify(oracle):
         assert np.array_equal(disparity, rd)
         assert np.array_equal(depth == 0, rz == 0)
         assert np.abs(depth - rz).max() <= DEPTH_TOL
+    # odd pixel counts, several images: the kernels work on pixel pairs (the last pixel of an image stands alone, the
+    # second image starts on an odd element)
+    d3 = rng.integers(-16, 128 * 16, (3, 51, 71)).astype(np.int16)
+    m3 = rng.random((51, 71)) < 0.9
+    disparity, depth = imgproc.disp_to_depth(torch.from_numpy(d3).cuda(), torch.from_numpy(m3.view(np.uint8)).cuda(), 2, 13,
+                                             True, 0.12 * 1536.0, 3.5)
+    for i in range(3):
+        rd, rz = oracle.disp_to_depth(d3[i], m3, 2, 13, True, 0.12 * 1536.0, 3.5)
+        assert np.array_equal(disparity[i].cpu().numpy(), rd) and np.array_equal(depth[i].cpu().numpy(), rz)
+    odd = (rng.integers(-2, 60, (2, 33, 41)) * 16).astype(np.int16)
+    got = imgproc.medianBlur3_s16(torch.from_numpy(odd).cuda()).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.median3_s16(odd[i]))
     depth = rng.uniform(0, 5, (h, w))
     mapx, mapy = _maps(rng, 44, 66, w, h, 3.0)
     M = np.array([0.0123, -0.0045, 0.9991])
