@@ -863,17 +863,18 @@ static int auto_concurrent_pairs(const Geom& g, bool band_ok, int max_batch)
 {
     int cap = max_batch < CAMD_MULTI_MAX_BATCH ? max_batch : CAMD_MULTI_MAX_BATCH;
     int n = (int)(auto_concurrent_limit(g) / pair_work(g));
-    // geometries without a band instantiation (D <= 32 or > 256) have no other fast path: the same work-based bound on
+    // geometries without a band instantiation (D > 256) have no other fast path: the same work-based bound on
     // the workspace (npaths volumes per pair), but never below one pair
     if (!band_ok && n < 1) n = 1;
     return n < cap ? n : cap;
 }
 
-// The band passes are instantiated for 16 lanes x {1,2} vectors and 8 lanes x 1 vector per pixel; their inline
-// winner-take-all (not used by MODE_SGBM_3WAY, which decides its winners in k_wta) covers uniquenessRatio <= 99.
+// The band passes are instantiated for 16 lanes x {1,2} vectors and 8 / 4 / 2 lanes x 1 vector per pixel (every
+// numDisparities up to 256); their inline winner-take-all (not used by MODE_SGBM_3WAY, which decides its winners in
+// k_wta) covers uniquenessRatio <= 99.
 static bool band_supported(const Geom& g)
 {
-    const bool shape = g.W1 > 0 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes == 8 && g.nv == 1));
+    const bool shape = g.W1 > 0 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes <= 8 && g.nv == 1));
     return shape && (g.mode == CAMD_MODE_SGBM_3WAY || g.uniq <= 99);
 }
 
@@ -961,7 +962,9 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     do {                                                               \
         if (g.lanes == 16 && g.nv == 1) CAMD_BAND(16, 1, FF, MM, DG);  \
         else if (g.lanes == 16) CAMD_BAND(16, 2, FF, MM, DG);          \
-        else CAMD_BAND(8, 1, FF, MM, DG);                              \
+        else if (g.lanes == 8) CAMD_BAND(8, 1, FF, MM, DG);            \
+        else if (g.lanes == 4) CAMD_BAND(4, 1, FF, MM, DG);            \
+        else CAMD_BAND(2, 1, FF, MM, DG);                              \
     } while (0)
     if (full && mode == 0 && diag) CAMD_BAND_SHAPE(true, 0, true);
     else if (full && mode == 2 && diag) CAMD_BAND_SHAPE(true, 2, true);
@@ -975,7 +978,9 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     } while (0)
         if (g.lanes == 16 && g.nv == 1) CAMD_BAND_TIE(16, 1);
         else if (g.lanes == 16) CAMD_BAND_TIE(16, 2);
-        else CAMD_BAND_TIE(8, 1);
+        else if (g.lanes == 8) CAMD_BAND_TIE(8, 1);
+        else if (g.lanes == 4) CAMD_BAND_TIE(4, 1);
+        else CAMD_BAND_TIE(2, 1);
 #undef CAMD_BAND_TIE
     }
     else if (!full && mode == 2) CAMD_BAND_SHAPE(false, 2, true);
