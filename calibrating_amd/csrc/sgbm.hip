@@ -1484,6 +1484,13 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     if (path == CAMD_PATH_BAND && !h->band_ok) path = CAMD_PATH_SCAN;
     // the per-direction volumes were sized in create / set_option: a larger batch takes the next best path
     if (path == CAMD_PATH_CONCURRENT && batch > mcap) path = h->band_ok ? CAMD_PATH_BAND : CAMD_PATH_SCAN;
+    // At 4 or 2 lanes per pixel (numDisparities <= 32) a band is 112 or 224 rows high: an image has only a handful of
+    // bands, and with few pairs the wavefront occupies a fraction of the chip.  Measured (tools/gpu_small_d_paths.sh,
+    // scans / band passes in pairs/s): 1080p D=32 8 pairs 1585 / 1294, 16 pairs 1673 / 2202; 1080p D=16 16 pairs
+    // 2407 / 1964, 32 pairs 2672 / 3170; VGA D=16 16 pairs 9980 / 6430, 64 pairs 17060 / 18530 -- the band passes win
+    // from about 128 workgroups on.
+    if (h->path == CAMD_PATH_AUTO && path == CAMD_PATH_BAND && g.lanes <= 4 && (long long)h->nbands * vbatch < 128)
+        path = CAMD_PATH_SCAN;
     const bool band = path == CAMD_PATH_BAND;
     const bool multi = path == CAMD_PATH_CONCURRENT;
     const size_t dir_stride = (size_t)mcap * h->vol_elems;
