@@ -1470,9 +1470,14 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     const int mcap = h->smulti_cap;
     int path = h->path;
     if (path == CAMD_PATH_AUTO) {
-        // the thresholds scale with the work per pair (in units of one 1080p / D=128 volume)
-        if (batch * pair_work(g) <= auto_concurrent_limit(g) || !h->band_ok) path = CAMD_PATH_CONCURRENT;
-        else path = CAMD_PATH_BAND;
+        // the thresholds scale with the work per pair (in units of one 1080p / D=128 volume) -- and the band passes
+        // also take over as soon as their workgroups fill the chip, however small the volumes (1280x720 D=128, 8 pairs
+        // = 3.4 units but 208 workgroups: 1645 pairs/s against 1277 on the concurrent scans, tools/gpu_mid_d_paths.sh;
+        // the two-wavefront modes need about twice as many)
+        const long long wgs = (long long)h->nbands * vbatch;
+        const bool fills = wgs >= ((g.mode == CAMD_MODE_HH || g.mode == CAMD_MODE_HH4) ? 300 : 150);
+        if (h->band_ok && (fills || batch * pair_work(g) > auto_concurrent_limit(g))) path = CAMD_PATH_BAND;
+        else path = CAMD_PATH_CONCURRENT;
     }
     if (way3) {
         // no per-direction volumes for the stripes: band passes, or three line scans + k_wta.  The wavefront of a
