@@ -855,17 +855,25 @@ static bool params_may_overflow(const Geom& g)
     return K * K * g.cn * (2 * g.ftzero + 63) + g.P2 > 32767;
 }
 
-// work of one pair in units of one 1080p / D=128 volume: the AUTO path rule and its workspace follow it
+// work of one pair in units of one 1080p / D=128 volume
 static double pair_work(const Geom& g) { return ((double)g.H * g.W1 * g.Dp) / (1080.0 * 1792.0 * 128.0); }
 static double auto_concurrent_limit(const Geom& g) { return g.mode == CAMD_MODE_HH ? 8.0 : 4.0; }
-// largest batch the AUTO rule sends down the concurrent-direction path (it needs npaths volumes per pair)
-static int auto_concurrent_pairs(const Geom& g, bool band_ok, int max_batch)
+// The band passes win on throughput once their workgroups -- bands x (virtual) pairs -- fill the chip; below that
+// the wavefront of a pass fills and drains over a mostly idle GPU and the line scans win (concurrently into their own
+// volumes while there is room for them, one launch per direction otherwise).  Measured crossovers (r03_batch_sweep,
+// tools/gpu_mid_d_paths.sh, tools/gpu_small_d_paths.sh, tools/gpu_get_depth_sweep.py): 1080p D=128 between 3 and 4
+// pairs (117 / 156 workgroups), MODE_HH at 8 (312); 720p D=128 8 pairs (208) band +29 %; 720p D=64 8 pairs (104)
+// scans +19 %; 4K D=64 2 pairs (78) scans.  The two-wavefront modes need about twice as many.
+static int band_fill_workgroups(const Geom& g) { return (g.mode == CAMD_MODE_HH || g.mode == CAMD_MODE_HH4) ? 300 : 150; }
+// largest batch the AUTO rule sends down the concurrent-direction path (it needs npaths volumes per pair): the
+// batches whose band passes would not fill the chip; at least one pair, at most CAMD_MULTI_MAX_BATCH
+static int auto_concurrent_pairs(const Geom& g, bool band_ok, int max_batch, int nbands)
 {
     int cap = max_batch < CAMD_MULTI_MAX_BATCH ? max_batch : CAMD_MULTI_MAX_BATCH;
-    int n = (int)(auto_concurrent_limit(g) / pair_work(g));
-    // geometries without a band instantiation (D > 256) have no other fast path: the same work-based bound on
-    // the workspace (npaths volumes per pair), but never below one pair
-    if (!band_ok && n < 1) n = 1;
+    int n;
+    if (band_ok && nbands > 0) n = (band_fill_workgroups(g) - 1) / nbands;  // pairs with fewer workgroups than that
+    else n = (int)(auto_concurrent_limit(g) / pair_work(g));                   // no band instantiation (D > 256)
+    if (n < 1) n = 1;
     return n < cap ? n : cap;
 }
 
@@ -1094,7 +1102,8 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     }
     // per-direction volumes: the latency path's, and one set of int volumes for the exact aggregation where the
     // parameters allow an int16 overflow of the cost volume (sgbm_exact.hpp)
-    if (!way3) total += (size_t)g.npaths * auto_concurrent_pairs(g, band_ok, max_batch) * vol;
+    if (!way3)
+        total += (size_t)g.npaths * auto_concurrent_pairs(g, band_ok, max_batch, div_up(vrows, BAND_THREADS / g.lanes)) * vol;
     if (w1 > 0 && params_may_overflow(g)) total += (size_t)g.npaths * vol * 2;
     return total;
 }
@@ -1171,7 +1180,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     // sequential scans take over), and without the one set the exact aggregation needs a flagged volume is refused
     // loudly (k_poison_flagged) instead
     if (e == hipSuccess && w1 > 0) {
-        int cap = way3 ? 0 : auto_concurrent_pairs(g, h->band_ok, max_batch);
+        int cap = way3 ? 0 : auto_concurrent_pairs(g, h->band_ok, max_batch, h->nbands);
         while (cap > 0) {
             if (hipMalloc((void**)&h->Smulti, (size_t)g.npaths * cap * h->vol_elems * 2) == hipSuccess) break;
             (void)hipGetLastError();
@@ -1470,13 +1479,8 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     const int mcap = h->smulti_cap;
     int path = h->path;
     if (path == CAMD_PATH_AUTO) {
-        // the thresholds scale with the work per pair (in units of one 1080p / D=128 volume) -- and the band passes
-        // also take over as soon as their workgroups fill the chip, however small the volumes (1280x720 D=128, 8 pairs
-        // = 3.4 units but 208 workgroups: 1645 pairs/s against 1277 on the concurrent scans, tools/gpu_mid_d_paths.sh;
-        // the two-wavefront modes need about twice as many)
-        const long long wgs = (long long)h->nbands * vbatch;
-        const bool fills = wgs >= ((g.mode == CAMD_MODE_HH || g.mode == CAMD_MODE_HH4) ? 300 : 150);
-        if (h->band_ok && (fills || batch * pair_work(g) > auto_concurrent_limit(g))) path = CAMD_PATH_BAND;
+        // band passes when their workgroups fill the chip (band_fill_workgroups), else the concurrent scans
+        if (h->band_ok && (long long)h->nbands * vbatch >= band_fill_workgroups(g)) path = CAMD_PATH_BAND;
         else path = CAMD_PATH_CONCURRENT;
     }
     if (way3) {
@@ -1487,13 +1491,14 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         else if (path != CAMD_PATH_SCAN) path = CAMD_PATH_BAND;
     }
     if (path == CAMD_PATH_BAND && !h->band_ok) path = CAMD_PATH_SCAN;
-    // the per-direction volumes were sized in create / set_option: a larger batch takes the next best path
-    if (path == CAMD_PATH_CONCURRENT && batch > mcap) path = h->band_ok ? CAMD_PATH_BAND : CAMD_PATH_SCAN;
+    // the per-direction volumes were sized in create / set_option: a larger batch takes the next best path -- the band
+    // passes when they at least come close to filling the chip, else one scan launch per direction
+    if (path == CAMD_PATH_CONCURRENT && batch > mcap)
+        path = (h->band_ok && (h->path != CAMD_PATH_AUTO || (long long)h->nbands * vbatch >= 128)) ? CAMD_PATH_BAND : CAMD_PATH_SCAN;
     // At 4 or 2 lanes per pixel (numDisparities <= 32) a band is 112 or 224 rows high: an image has only a handful of
-    // bands, and with few pairs the wavefront occupies a fraction of the chip.  Measured (tools/gpu_small_d_paths.sh,
-    // scans / band passes in pairs/s): 1080p D=32 8 pairs 1585 / 1294, 16 pairs 1673 / 2202; 1080p D=16 16 pairs
-    // 2407 / 1964, 32 pairs 2672 / 3170; VGA D=16 16 pairs 9980 / 6430, 64 pairs 17060 / 18530 -- the band passes win
-    // from about 128 workgroups on.
+    // bands (tools/gpu_small_d_paths.sh, scans / band passes in pairs/s: 1080p D=32 8 pairs 1585 / 1294, 16 pairs
+    // 1673 / 2202; VGA D=16 16 pairs 9980 / 6430, 64 pairs 17060 / 18530): same rule, the band passes from ~128
+    // workgroups on
     if (h->path == CAMD_PATH_AUTO && path == CAMD_PATH_BAND && g.lanes <= 4 && (long long)h->nbands * vbatch < 128)
         path = CAMD_PATH_SCAN;
     const bool band = path == CAMD_PATH_BAND;
