@@ -794,7 +794,9 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
         set_error("blockSize %d > %d not implemented", bs, HSUM_RING - 1);
         return CAMD_ERR_UNSUPPORTED;
     }
-    if (g->P2 > 16000 || g->ftzero > 127) {
+    // (P2: cv2's rule of thumb 32 * cn * blockSize^2 is 21600 at block 15 RGB; the fuzz covers the range up to the
+    // limit -- in the last few per cent below 32767 the exact int path meets narrowings it does not restate)
+    if (g->P2 > 24000 || g->ftzero > 127) {
         set_error("P2 = %d / preFilterCap = %d outside the int16 regime the kernels implement", g->P2,
                   p->preFilterCap);
         return CAMD_ERR_UNSUPPORTED;
@@ -1405,7 +1407,6 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         } else {
             launch_cost(sat, nullptr, -1);
         }
-        // (K <= 3 cannot overflow: 9 * 3 * 317 + 16000 < 32768)
         CAMD_LAUNCH_CHECK();
     }
     MARK(ST_HSUM);

@@ -58,6 +58,8 @@ def test_sgbm_edge_shapes(oracle, H, W, D, cn, bs, minD, mode):
     dict(uniquenessRatio=0), dict(uniquenessRatio=50), dict(uniquenessRatio=99), dict(uniquenessRatio=-5),
     dict(disp12MaxDiff=-1), dict(disp12MaxDiff=10), dict(P1=1, P2=2), dict(P1=3000, P2=9000),
     dict(preFilterCap=63), dict(preFilterCap=5), dict(speckleWindowSize=50, speckleRange=4),
+    # cv2's rule of thumb P1 = 8 cn b^2, P2 = 32 cn b^2 at the largest block of an RGB pair; the library's P2 limit
+    dict(blockSize=15, P1=5400, P2=21600), dict(blockSize=15, P1=5400, P2=21600, preFilterCap=63), dict(P1=10, P2=24000),
 ])
 def test_sgbm_parameter_extremes(oracle, kw):
     left, right = synthetic.rectified_pair(seed=17, H=36, W=220, D=64, cn=3)

@@ -25,7 +25,9 @@ for case in range(n):
     W = D + abs(minD) + int(rng.integers(b // 2 + 2, 140))
     H = int(rng.integers(3, 90)) if mode != 2 else int(rng.integers(40, 110))
     P1 = int(rng.integers(1, 8 * cn * b * b + 2))
-    P2 = min(P1 + int(rng.integers(1, 32 * cn * b * b + 2)), 15000)
+    P2 = P1 + int(rng.integers(1, 32 * cn * b * b + 2))
+    if rng.random() < 0.3:  # up to the library's limit (cv2's rule of thumb 32*cn*b*b is 21600 at block 15 RGB)
+        P2 = int(rng.integers(max(P1 + 1, 12000), 24001))
     p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=P1, P2=P2, disp12MaxDiff=int(rng.integers(-1, 4)),
              uniquenessRatio=int(rng.integers(0, 30)), preFilterCap=int(rng.choice([0, 15, 31, 63])),
              speckleWindowSize=int(rng.choice([0, 0, 40])), speckleRange=int(rng.integers(1, 4)), mode=mode)
