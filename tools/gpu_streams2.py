@@ -6,7 +6,7 @@ import calibrating_amd as ca
 from calibrating_amd import synthetic
 dev = torch.device('cuda', 0)
 P = dict(minDisparity=0, numDisparities=128, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1, uniquenessRatio=10)
-N = 64
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 L, R = synthetic.rectified_batch_torch(1234, N, 1080, 1920, 128, 3, dev)
 
 def bench(name, step, reps=5):
