@@ -60,7 +60,11 @@ typedef struct camd_sgbm camd_sgbm;
 /* Workspace (device) bytes a handle for these sizes allocates. 0 on bad arguments. */
 size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int height, int channels,
                                  int max_batch);
-/* Allocates the per-pair workspace for `max_batch` pairs of width x height x channels (1 or 3) u8. */
+/* Allocates the per-pair workspace for `max_batch` pairs of width x height x channels (1 or 3) u8.
+ * Parameters are normalised as cv2 does (numDisparities rounded up to 16, P1 / P2 defaults, blockSize made odd ...).
+ * Refused with CAMD_ERR_UNSUPPORTED and a message, never computed differently: numDisparities > 512, blockSize > 15
+ * (> 11 for MODE_SGBM_3WAY), P2 > 24000, preFilterCap > 127, 0 < width - numDisparities <= blockSize / 2 (cv2's own
+ * result is undefined there), MODE_SGBM_3WAY on images too low for its four stripes. */
 int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int channels, int max_batch,
                      camd_sgbm** out);
 int camd_sgbm_destroy(camd_sgbm* h);
