@@ -86,6 +86,8 @@ SIGNATURES = {
     "camd_resize_linear_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "camd_disp_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double,
                                    c_double, c_void_p, c_void_p, c_int, c_void_p]),
+    "camd_disp16_resized_to_depth": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                             c_double, c_double, c_void_p, c_void_p, c_int, c_void_p]),
     "camd_unrectify_depth": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_void_p]),
 }

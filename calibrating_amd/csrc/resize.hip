@@ -97,6 +97,48 @@ __global__ __launch_bounds__(256) void k_resize_f32(const float* __restrict__ sr
     *o = __fadd_rn(__fmul_rn(h0, b0), __fmul_rn(h1, b1));
 }
 
+// The matcher's downsizing branch in one pass (stereo_matching.py:63-69 with max_size < image, stereo_camera.py:510-513,
+// :408-413): the int16 disparity of the DOWNSIZED pair -> float32, clip at 0, below minDisparity*16 -> 0, /16 (all
+// on the fly, per source tap), cv2.resize(INTER_LINEAR) up to the rectified size, * w / sw, += min_disparity, * mask,
+// depth = baseline*fx / disparity with the two clamps.  Replaces k_resize_f32 and a dozen elementwise launches; every
+// float operation is the one NumPy / cv2 performs, in their order.
+__global__ __launch_bounds__(256) void k_disp16_up_to_depth(const int16_t* __restrict__ src, int sw, int sh,
+                                                            const uint8_t* __restrict__ mask, int dw, int dh,
+                                                            double scx, double scy, float thresh, float addv,
+                                                            int translate, float wf, float swf, double bf,
+                                                            double max_depth, float* __restrict__ disparity,
+                                                            double* __restrict__ depth)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    const int16_t* s = src + (size_t)blockIdx.z * sw * sh;
+    auto tap = [&](const int16_t* p) {
+        float v = (float)*p;
+        v = v < 0.f ? 0.f : v;
+        v = v < thresh ? 0.f : v;
+        return v / 16.0f;
+    };
+    const Axis ax = axis_x(x, scx, sw), ay = axis_y(y, scy);
+    const int sy0 = min(max(ay.s, 0), sh - 1), sy1 = min(max(ay.s + 1, 0), sh - 1);
+    const float a0 = __fsub_rn(1.f, ax.f), a1 = ax.f, b0 = __fsub_rn(1.f, ay.f), b1 = ay.f;
+    const int16_t* r0 = s + (size_t)sy0 * sw + ax.s;
+    const int16_t* r1 = s + (size_t)sy1 * sw + ax.s;
+    float h0, h1;
+    if (!ax.edge) {
+        h0 = __fadd_rn(__fmul_rn(tap(r0), a0), __fmul_rn(tap(r0 + 1), a1));
+        h1 = __fadd_rn(__fmul_rn(tap(r1), a0), __fmul_rn(tap(r1 + 1), a1));
+    } else { h0 = tap(r0); h1 = tap(r1); }
+    float d = __fadd_rn(__fmul_rn(h0, b0), __fmul_rn(h1, b1));
+    d = __fdiv_rn(__fmul_rn(d, wf), swf);  // * w / sw, each op rounded like NumPy
+    if (translate) d = __fadd_rn(d, addv);
+    const size_t i = (size_t)y * dw + x, o = (size_t)blockIdx.z * dw * dh + i;
+    d = mask[i] ? d : __fmul_rn(0.f, d);
+    disparity[o] = d;
+    double z = __ddiv_rn(bf, (double)d);
+    z = z > max_depth ? 0. : z;
+    depth[o] = z < 0. ? 0. : z;
+}
+
 }  // namespace camd
 
 using namespace camd;
@@ -143,6 +185,28 @@ int camd_resize_linear_f32(const float* src, int sw, int sh, float* dst, int dw,
     const double scx = (double)sw / dw, scy = (double)sh / dh;
     hipLaunchKernelGGL(k_resize_f32, dim3(div_up(dw, 256), dh, batch), dim3(256), 0, st, src, sw, sh, dst, dw, dh,
                        scx, scy, area2);
+    CAMD_LAUNCH_CHECK();
+    return CAMD_OK;
+}
+
+int camd_disp16_resized_to_depth(const int16_t* disp16, int sw, int sh, const uint8_t* valid_mask, int w, int h,
+                                 int sgbm_min_disparity, int add_min_disparity, int translate, double baseline_fx,
+                                 double max_depth, float* disparity, double* depth, int batch, void* stream)
+{
+    if (!disp16 || !valid_mask || !disparity || !depth || sw <= 0 || sh <= 0 || w <= 0 || h <= 0 || batch <= 0) {
+        set_error("camd_disp16_resized_to_depth: bad arguments");
+        return CAMD_ERR_BAD_ARG;
+    }
+    if (sw == w * 2 && sh == h * 2) {  // (cv2.resize takes its 2x2 area path there; the matcher never upsizes by 1/2)
+        set_error("camd_disp16_resized_to_depth: exact 2:1 reduction is not a case of the matcher's resize back");
+        return CAMD_ERR_UNSUPPORTED;
+    }
+    int rc = camd_device_ok();
+    if (rc != CAMD_OK) return rc;
+    hipLaunchKernelGGL(k_disp16_up_to_depth, dim3(div_up(w, 256), h, batch), dim3(256), 0, (hipStream_t)stream, disp16, sw,
+                       sh, valid_mask, w, h, (double)sw / w, (double)sh / h, (float)(sgbm_min_disparity * 16),
+                       (float)add_min_disparity, translate, (float)w, (float)sw, baseline_fx, max_depth, disparity,
+                       depth);
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
 }

@@ -194,6 +194,31 @@ def disp_to_depth(disp16, valid_mask, sgbm_min_disparity, add_min_disparity, tra
     return disparity, depth
 
 
+def disp16_resized_to_depth(sdisp16, hw, valid_mask, sgbm_min_disparity, add_min_disparity, translate, baseline_fx,
+                            max_depth):
+    """The matcher's downsizing branch (stereo_matching.py:63-69 with max_size < image) + stereo_camera.py:510-513 +
+    :408-413 in one pass: ``sdisp16`` is the int16 disparity of the downsized pair(s), ``hw`` the rectified size.
+    Returns (disparity float32, rectify_depth float64) at ``hw``.  CUDA tensors only."""
+    import torch
+    d, _ = _to_dev(sdisp16, torch.int16)
+    m, _ = _to_dev(valid_mask)
+    if m.dtype == torch.bool:
+        m = m.view(torch.uint8)
+    sh, sw = d.shape[-2:]
+    n = d.numel() // (sh * sw)
+    h, w = int(hw[0]), int(hw[1])
+    disparity = torch.empty(d.shape[:-2] + (h, w), dtype=torch.float32, device=d.device)
+    depth = torch.empty(d.shape[:-2] + (h, w), dtype=torch.float64, device=d.device)
+    with torch.cuda.device(d.device):
+        rc = _native.lib().camd_disp16_resized_to_depth(d.data_ptr(), sw, sh, m.data_ptr(), w, h,
+                                                        int(sgbm_min_disparity), int(add_min_disparity),
+                                                        int(bool(translate)), ctypes.c_double(baseline_fx),
+                                                        ctypes.c_double(max_depth), disparity.data_ptr(),
+                                                        depth.data_ptr(), n, _native.current_stream())
+    _native.check(rc, "disp16_resized_to_depth")
+    return disparity, depth
+
+
 def unrectify_depth(depth, M_row2, mapx, mapy):
     """utils.rotate_depth_by_remap (utils.py:192-199): z-rescale + INTER_NEAREST remap, float64."""
     import torch

@@ -283,11 +283,15 @@ class Stereo:
             return sm
         return None
 
-    def _fused_depth(self, sm, disp16, tables):
-        # matcher post-processing, += min_disparity, * mask and disparity_to_depth in one kernel
-        return imgproc.disp_to_depth(disp16, tables["mask"], sm.stereo_sgbm.getMinDisparity(), self.min_disparity,
-                                     bool(self.translation_rectify_img), 1.0 * self.baseline * self.K[0, 0],
-                                     self.get_max_depth())
+    def _fused_depth(self, sm, disp16, tables, hw=None):
+        """Matcher post-processing, += min_disparity, * mask and disparity_to_depth in one kernel.  ``hw``: the rectified
+        size when ``disp16`` belongs to a DOWNSIZED pair (cfg["max_size"] below the image: the reference's default):
+        the resize back (stereo_matching.py:66) is then part of the same pass."""
+        args = (tables["mask"], sm.stereo_sgbm.getMinDisparity(), self.min_disparity, bool(self.translation_rectify_img),
+                1.0 * self.baseline * self.K[0, 0], self.get_max_depth())
+        if hw is not None and tuple(hw) != tuple(disp16.shape[-2:]):
+            return imgproc.disp16_resized_to_depth(disp16, hw, *args)
+        return imgproc.disp_to_depth(disp16, *args)
 
     def get_depth(self, img1, img2, return_unrectify_depth=True, return_distort_depth=False):
         """Return dict: rectify_img1, rectify_depth, disparity, rectify_img2 (+ unrectify_depth,
@@ -318,11 +322,12 @@ class Stereo:
         if sm is not None:
             disp16, _ = sm.compute_disp16(rectify_img1, rectify_img2)
             disparity, rectify_depth = self._fused_depth(sm, disp16, tb)
+        elif isinstance(plugin, SemiGlobalBlockMatching):  # the downsizing matcher: resize, match, resize back + post
+            sdisp16, _ = plugin.compute_disp16(rectify_img1, rectify_img2)
+            disparity, rectify_depth = self._fused_depth(plugin, sdisp16, tb, rectify_img1.shape[:2])
         else:
-            if isinstance(plugin, SemiGlobalBlockMatching):  # downsizing SGBM: stays on the GPU
-                disparity = plugin(rectify_img1, rectify_img2)
-            else:  # foreign plugin: the reference's contract is NumPy in, NumPy (or dict) out
-                disparity = plugin(*hostio.to_host(rectify_img1, rectify_img2))
+            # foreign plugin: the reference's contract is NumPy in, NumPy (or dict) out
+            disparity = plugin(*hostio.to_host(rectify_img1, rectify_img2))
             if isinstance(disparity, dict):
                 result.update({k: v for k, v in disparity.items() if k != "disparity"})
                 disparity = disparity["disparity"]
@@ -359,18 +364,14 @@ class Stereo:
         if not isinstance(self.stereo_matching, SemiGlobalBlockMatching):
             raise ValueError("get_depth_batch needs a SemiGlobalBlockMatching plugin")
         rectify_img1, rectify_img2 = self.rectify(i1, i2)
-        import torch
         sm = self._sgbm_full_res(rectify_img1.shape[1:3])
         tb = self._tables(i1.device)
         if sm is not None:
             disparity, rectify_depth = self._fused_depth(sm, sm.stereo_sgbm.compute(rectify_img1, rectify_img2), tb)
-        else:  # the downsizing matcher, stage by stage like get_depth's general branch
+        else:  # the downsizing matcher: batched resize, match, resize back + post-processing in one pass
             sm = self.stereo_matching
-            disparity = sm.call_batch(rectify_img1, rectify_img2)
-            if self.translation_rectify_img:
-                disparity += self.min_disparity
-            disparity = tb["mask"].to(torch.bool) * disparity
-            rectify_depth = self.disparity_to_depth(disparity)
+            sdisp16, _ = sm.compute_disp16(rectify_img1, rectify_img2, batched=True)
+            disparity, rectify_depth = self._fused_depth(sm, sdisp16, tb, rectify_img1.shape[1:3])
         result = dict(rectify_img1=rectify_img1, rectify_depth=rectify_depth, disparity=disparity,
                       rectify_img2=rectify_img2)
         if return_unrectify_depth:

@@ -193,6 +193,14 @@ int camd_disp_to_depth(const int16_t* disp16, const uint8_t* valid_mask, int w, 
                        int sgbm_min_disparity, int add_min_disparity, int translate,
                        double baseline_fx, double max_depth, float* disparity, double* depth,
                        int batch, void* stream);
+/* The same for the matcher's downsizing branch (cfg["max_size"] < max(h, w), the reference's default 1000):
+ * disp16 is the int16 disparity of the sw x sh DOWNSIZED pair; stereo_matching.py:63-69 in full -- float32, clip,
+ * < minD*16 -> 0, /16, boxx.resize (cv2.resize INTER_LINEAR) back to w x h, * w / sw -- then stereo_camera.py:510-513
+ * and :408-413 as above, one pass.                                                                                  */
+int camd_disp16_resized_to_depth(const int16_t* disp16, int sw, int sh, const uint8_t* valid_mask, int w, int h,
+                                 int sgbm_min_disparity, int add_min_disparity, int translate,
+                                 double baseline_fx, double max_depth, float* disparity, double* depth,
+                                 int batch, void* stream);
 /* replaces utils.rotate_depth_by_remap (utils.py:192-199) as called by Stereo.unrectify_depth
  * (stereo_camera.py:415-428): z' = M20*(u*z) + M21*(v*z) + M22*z, then INTER_NEAREST remap.      */
 int camd_unrectify_depth(const double* depth, int w, int h, const double M_row2_host[3],
