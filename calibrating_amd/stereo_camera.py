@@ -276,10 +276,20 @@ class Stereo:
         self.min_disparity = int(self.cam1.K[0, 0] * self.baseline / self.max_depth)
         return self
 
+    def _native_sgbm(self):
+        """The installed plugin if it is this package's SGBM plugin with ITS OWN ``__call__`` -- only then may the stages
+        after the match be fused on the device.  A subclass that overrides ``__call__`` (extra result keys, its own
+        post-filter) goes through ``plugin(img1, img2)`` like any foreign plugin, as in the reference
+        (stereo_camera.py:506-509)."""
+        sm = self.stereo_matching
+        if isinstance(sm, SemiGlobalBlockMatching) and type(sm).__call__ is SemiGlobalBlockMatching.__call__:
+            return sm
+        return None
+
     def _sgbm_full_res(self, rectified_hw):
         """The SGBM plugin when it runs at the rectified resolution (no max_size downsizing), else None."""
-        sm = self.stereo_matching
-        if isinstance(sm, SemiGlobalBlockMatching) and min(sm.max_size / max(rectified_hw), 1) == 1:
+        sm = self._native_sgbm()
+        if sm is not None and min(sm.max_size / max(rectified_hw), 1) == 1:
             return sm
         return None
 
@@ -322,7 +332,7 @@ class Stereo:
         if sm is not None:
             disp16, _ = sm.compute_disp16(rectify_img1, rectify_img2)
             disparity, rectify_depth = self._fused_depth(sm, disp16, tb)
-        elif isinstance(plugin, SemiGlobalBlockMatching):  # the downsizing matcher: resize, match, resize back + post
+        elif self._native_sgbm() is not None:  # the downsizing matcher: resize, match, resize back + post
             sdisp16, _ = plugin.compute_disp16(rectify_img1, rectify_img2)
             disparity, rectify_depth = self._fused_depth(plugin, sdisp16, tb, rectify_img1.shape[:2])
         else:
@@ -359,10 +369,12 @@ class Stereo:
         assert hasattr(self, "stereo_matching"), "Please stereo.set_stereo_matching(stereo_matching)"
         i1, was_np = self._to_dev(imgs1)
         i2, _ = self._to_dev(imgs2)
-        if i1.dim() != 4 or i1.shape != i2.shape:
-            raise ValueError("imgs1 / imgs2 must be (n, h, w, c) arrays of equal shape")
-        if not isinstance(self.stereo_matching, SemiGlobalBlockMatching):
-            raise ValueError("get_depth_batch needs a SemiGlobalBlockMatching plugin")
+        # (the two cameras of a rig may differ in resolution -- each is rectified through its own maps,
+        # stereo_camera.py:159-165,216-228 -- so only the pair count and the channel count have to agree)
+        if i1.dim() != 4 or i2.dim() != 4 or i1.shape[0] != i2.shape[0] or i1.shape[3] != i2.shape[3]:
+            raise ValueError("imgs1 / imgs2 must be (n, h, w, c) stacks of the same number of pairs and channels")
+        if self._native_sgbm() is None:
+            raise ValueError("get_depth_batch needs the SemiGlobalBlockMatching plugin (with its own __call__)")
         rectify_img1, rectify_img2 = self.rectify(i1, i2)
         sm = self._sgbm_full_res(rectify_img1.shape[1:3])
         tb = self._tables(i1.device)

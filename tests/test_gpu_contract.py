@@ -70,6 +70,39 @@ def test_foreign_plugin_contract(oracle, as_dict, max_depth):
                                                                               "rectify_img2"}
 
 
+class _PostFilteringSGBM(ca.SemiGlobalBlockMatching):
+    """A user's subclass of the SGBM plugin that overrides ``__call__``: returns a dict with an extra key and its own
+    post-filter.  The reference always goes through ``stereo_matching(img1, img2)`` (stereo_camera.py:506-509), so the
+    override must be honoured at full resolution AND in the max_size downsizing branch (no fused shortcut around it)."""
+
+    def __call__(self, img1, img2):
+        disparity = super().__call__(img1, img2)
+        assert isinstance(disparity, np.ndarray), "the plugin contract is NumPy in, NumPy out"
+        disparity[disparity > 40] = 0
+        return dict(disparity=disparity, filtered_by="subclass")
+
+
+@pytest.mark.parametrize("max_size", [320, 200])
+def test_sgbm_subclass_override_is_honoured(oracle, max_size):
+    from oracle_pipeline import matcher_disparity, rectified_pair
+    W, H = 320, 240
+    rec = synthetic.rig(W, H)
+    stereo = ca.Stereo.load(rec)
+    cfg = dict(max_size=max_size, minDisparity=0, numDisparities=64, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+               uniquenessRatio=10, speckleWindowSize=0)
+    stereo.set_stereo_matching(_PostFilteringSGBM(cfg), max_depth=None)
+    img1, img2, _ = synthetic.render_plane_pair(rec, (0.3, 0.1, 1.0), 2.0)
+    got = stereo.get_depth(img1, img2)
+    assert got["filtered_by"] == "subclass"
+    r1, r2, mask = rectified_pair(oracle, stereo, img1, img2)
+    want = matcher_disparity(oracle, cfg, r1, r2)
+    assert (want > 40).any() and (want > 0).mean() > 0.5
+    want[want > 40] = 0
+    assert np.array_equal(got["disparity"], mask * want)
+    with pytest.raises(ValueError, match="own __call__"):
+        stereo.get_depth_batch(np.stack([img1, img1]), np.stack([img2, img2]))
+
+
 @pytest.mark.parametrize("xy_target,K_target", [(0.5, 0.5), ((400, 260), 1), (None, 0.8), (1.25, 1)])
 def test_get_depth_with_resized_rectified_frame(oracle, xy_target, K_target):
     """Rectified size != source size (reference stereo_camera.py:125-156: xy_target / K_target), single and batched."""

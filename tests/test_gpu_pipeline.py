@@ -208,23 +208,10 @@ def test_disp_to_depth_and_unrectify(oracle):
 
 
 def _oracle_get_depth(oracle, stereo, sgbm_params, img1, img2):
-    """The reference's get_depth (stereo_camera.py:492-533) composed from oracle stages."""
-    shift = stereo.min_disparity if stereo.translation_rectify_img else 0
-    r1 = oracle.remap_u8(img1, *stereo.undistort_rectify_map1, oracle.INTER_LANCZOS4)
-    r2 = oracle.remap_u8(img2, *stereo.undistort_rectify_map2, oracle.INTER_LANCZOS4)
-    if shift > 0:
-        r2[:, shift:] = r2[:, :-shift].copy()
-        r2[:, :shift] = 0
-    disp16 = oracle.sgbm_compute(r1, r2, **sgbm_params)
-    disparity, depth = oracle.disp_to_depth(disp16, stereo.rectify_valid_mask1, sgbm_params["minDisparity"],
-                                            stereo.min_disparity, stereo.translation_rectify_img,
-                                            1.0 * stereo.baseline * stereo.K[0, 0], stereo.get_max_depth())
-    maps = oracle.init_undistort_rectify_map(stereo.K, None, stereo.R1.T, stereo.cam1.K, stereo.cam1.xy)
-    M = stereo.R1.T @ np.linalg.inv(stereo.K)
-    unrect = oracle.unrectify_depth(depth, M[2], *maps)
-    undist = oracle.undistort_u8(img1, stereo.cam1.K, stereo.cam1.D)
-    return dict(rectify_img1=r1, rectify_img2=r2, disparity=disparity, rectify_depth=depth,
-                unrectify_depth=unrect, undistort_img1=undist)
+    """The reference's get_depth (stereo_camera.py:492-533) composed from oracle stages at the matcher's full
+    resolution (tests/oracle_pipeline.py holds the composition, incl. the max_size downsizing branch)."""
+    from oracle_pipeline import oracle_get_depth
+    return oracle_get_depth(oracle, stereo, dict(sgbm_params, max_size=1 << 30), img1, img2)
 
 
 @pytest.mark.parametrize("W,H,max_depth", [(640, 480, None), (640, 480, 3.5), (320, 240, 3.0), (1920, 1080, 3.5)])

@@ -83,8 +83,12 @@ def test_default_plugin_config_with_max_size(oracle):
     want = oracle.resize_linear(sd / np.float32(16.0), (H, W)) * W / hw[1]
     assert got.shape == (H, W) and got.dtype == np.float32
     assert np.array_equal(got, want)  # float32 op for op like NumPy: * w, then a true division by sw
-    # and through Stereo.get_depth (non-fused branch of get_depth)
+    # and through Stereo.get_depth: the fused kernel k_disp16_up_to_depth behind the downsizing branch, against the
+    # oracle composition (tests/test_gpu_downsizing.py holds the full matrix of this branch)
+    from oracle_pipeline import compare, oracle_get_depth
     stereo = ca.Stereo.load(synthetic.rig(W, H))
     stereo.set_stereo_matching(m, max_depth=3.5)
     res = stereo.get_depth(left, right)
     assert res["unrectify_depth"].shape == (H, W) and res["disparity"].dtype == np.float32
+    bad, inexact = compare(res, oracle_get_depth(oracle, stereo, {}, left, right))
+    assert not bad and not inexact, (bad, inexact)

@@ -1,78 +1,20 @@
-"""Extended seeded fuzz of the SGBM path against the CPU oracle (run by hand on a GPU box: python tools/gpu_fuzz.py N).
-Random sizes (incl. widths that leave partial strips / single columns), channel counts, disparity ranges, block sizes
-up to 11, penalties, preFilterCap up to 63 (the saturating regime), all four modes, batches, both cost-kernel paths;
-every fifth case is built to drift out of the int16 regime (synthetic.drift_pair) and must still match bit for bit."""
+"""Extended seeded fuzz of the SGBM path against the CPU oracle, by hand on a GPU box:
+    CAMD_GIT_SHA=<sha> python tools/gpu_fuzz.py N [first_seed [n_seeds]]
+N cases for each of n_seeds consecutive seeds (tests/fuzzers.fuzz_sgbm holds the generator; the driver's GPU suite runs
+a bounded slice of the same).  Prints one FUZZ line per seed: git SHA, library hash, seed, per-branch counts, mismatches."""
 import os, sys
-import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: F401
-import calibrating_amd as ca
-import oracle
-from calibrating_amd import synthetic
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch  # noqa: F401,E402
+import oracle  # noqa: E402
+import fuzzers  # noqa: E402
 
 oracle.build()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
-bad = skipped = drift = 0
-for case in range(n):
-    cn = int(rng.choice([1, 3]))
-    D = int(rng.choice([8, 16, 24, 32, 48, 50, 64, 96, 128, 160, 200, 256, 300]))
-    bs = int(rng.choice([0, 1, 3, 5, 7, 9, 11]))
-    minD = int(rng.integers(-9, 10))
-    mode = int(rng.choice([0, 1, 2, 3]))
-    force_band = bool(rng.integers(0, 2))  # (AUTO sends small 3WAY calls down the scan path)
-    b = max(bs, 1)
-    W = D + abs(minD) + int(rng.integers(b // 2 + 2, 140))
-    H = int(rng.integers(3, 90)) if mode != 2 else int(rng.integers(40, 110))
-    P1 = int(rng.integers(1, 8 * cn * b * b + 2))
-    P2 = P1 + int(rng.integers(1, 32 * cn * b * b + 2))
-    if rng.random() < 0.3:  # up to the library's limit (cv2's rule of thumb 32*cn*b*b is 21600 at block 15 RGB)
-        P2 = int(rng.integers(max(P1 + 1, 12000), 24001))
-    p = dict(minDisparity=minD, numDisparities=D, blockSize=bs, P1=P1, P2=P2, disp12MaxDiff=int(rng.integers(-1, 4)),
-             uniquenessRatio=int(rng.integers(0, 30)), preFilterCap=int(rng.choice([0, 15, 31, 63])),
-             speckleWindowSize=int(rng.choice([0, 0, 40])), speckleRange=int(rng.integers(1, 4)), mode=mode)
-    kind = case % 5
-    if kind == 4:  # saturation in the upper part, none below: C drifts under P2 / negative -> the exact int path
-        left, right = synthetic.drift_pair(H, W, cn, split=float(rng.uniform(0.2, 0.8)), seed=case)
-        if cn == 1:
-            left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
-    elif kind == 0:
-        r2 = np.random.default_rng(case)
-        shape = (H, W) if cn == 1 else (H, W, cn)
-        left, right = r2.integers(0, 256, shape, dtype=np.uint8), r2.integers(0, 256, shape, dtype=np.uint8)
-    elif kind == 1:  # opposite sawtooth ramps: drives the window sums into saturation when preFilterCap is raised
-        x, y = np.arange(W)[None, :], np.arange(H)[:, None]
-        ramp = ((x * 16 + y * 40) % 256).astype(np.uint8)
-        left = ramp if cn == 1 else ramp[..., None].repeat(3, 2)
-        right = 255 - left
-    else:
-        left, right = synthetic.rectified_pair(seed=case, H=H, W=W, D=max(min(D, W // 2), 8), cn=cn)
-    try:
-        want = oracle.sgbm_compute(left, right, **p)
-    except ValueError:
-        skipped += 1
-        continue  # the oracle refuses (too narrow / too low for 3WAY): the product must refuse too
-    try:
-        for cost in ((1, 2) if mode != 2 and bs <= 11 else (0,)):
-            m = ca.StereoSGBM_create(**p)
-            m.set_option("cost", cost)
-            if mode == 2 and force_band:
-                m.set_option("path", 2)
-            nb = int(rng.choice([1, 1, 3]))
-            got = m.compute(np.stack([left] * nb), np.stack([right] * nb)) if nb > 1 else m.compute(left, right)[None]
-            if cost != 2 and nb == 1:
-                # how many cases leave the packed-u16 regime (C < P2 after an int16 overflow) and take the exact path
-                P2n = max(p["P2"] if p["P2"] > 0 else 5, (p["P1"] if p["P1"] > 0 else 2) + 1)
-                if mode != 2 and int(m.debug_volume("C").min()) < P2n:
-                    drift += 1
-            for i in range(nb):
-                if not np.array_equal(got[i], want):
-                    bad += 1
-                    print("MISMATCH case %d cost %d batch %d/%d %s %s: %d pixels" % (case, cost, i, nb, (H, W, cn), p,
-                                                                                   (got[i] != want).sum()))
-                    break
-    except ValueError as e:
-        print("case %d refused by the product only: %s %s %s" % (case, (H, W, cn), p, e))
-        bad += 1
-print("%d cases (%d refused by the oracle and skipped; at least %d left the packed-u16 regime -- C below P2 after an int16 "
-      "overflow -- and were aggregated by the exact int kernels), %d problems" % (n, skipped, drift, bad))
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 77
+total = 0
+for seed in range(first, first + (int(sys.argv[3]) if len(sys.argv) > 3 else 1)):
+    res = fuzzers.fuzz_sgbm(n, seed, log=lambda *a: print(*a, flush=True))
+    fuzzers.report(res, log=lambda *a: print(*a, flush=True))
+    total += len(res["mismatches"])
+sys.exit(1 if total else 0)
