@@ -65,15 +65,25 @@ int launch_median3(const int16_t* src, size_t sp, size_t ss, int16_t* dst, size_
 }
 
 // ---- union-find connected components --------------------------------------------------------------
+// Layout of the workspace: per image 2 * w * h ints = parent[w * h] then count[w * h]; node ids are pixel indices
+// local to the image.  INVARIANT between calls: every parent entry is -1 ("root of its own tree").  The kernels below
+// only ever write the entries of nodes -- the first pixel of a horizontal run inside a 64-pixel segment ("run start")
+// and a segment's last pixel -- and k_cc_apply puts every one of them back to -1, so nothing has to be initialised
+// per call (the owner of the workspace clears it once; see launch_speckle's `clean`).
 __device__ __forceinline__ int uf_find(int* parent, int a)
 {
-    int p = parent[a];
-    while (p != a) {
-        int gp = parent[p];
-        if (gp != p) parent[a] = gp;  // path halving (benign race: only ever points closer to the root)
+    while (true) {
+        const int p = parent[a];
+        if (p < 0) return a;
+        const int gp = parent[p];
+        if (gp >= 0) parent[a] = gp;  // path halving (benign race: only ever points closer to the root)
         a = p;
-        p = gp;
     }
+}
+
+__device__ __forceinline__ int uf_find_ro(const int* parent, int a)
+{
+    for (int p = parent[a]; p >= 0; p = parent[a]) a = p;
     return a;
 }
 
@@ -84,136 +94,206 @@ __device__ void uf_union(int* parent, int a, int b)
         b = uf_find(parent, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }  // a > b: hook the larger root under the smaller
-        int old = atomicCAS(&parent[a], a, b);
-        if (old == a) return;
-        a = old;
+        const int old = atomicCAS(&parent[a], -1, b);
+        if (old < 0) return;
+        a = old;  // someone hooked a first (or this lane's view of it was stale): carry on from its parent
     }
 }
 
-// All kernels: blockIdx.z = image of the batch; parent / count hold 2*n ints per image (labels are local); a block is
-// 256 consecutive pixels of one row, so a wave is 64 consecutive pixels.
+// Geometry of all four kernels: a wave owns a SEGMENT of 64 columns and walks a STRIP of CC_ROWS rows top to bottom
+// (a block = 4 neighbouring segments; blockIdx.y = strip, blockIdx.z = image).  One row per wave and launch -- the
+// round-3 form -- was bound by the rate at which waves start, not by memory: 553 K four-wave blocks of ~20
+// instructions per kernel.
 //
-// Horizontal structure comes for free: within a wave the pixels of a horizontal run (each connected to its left
-// neighbour) are found from one ballot, so
-//   k_cc_rows   points every pixel at the first pixel of its run-in-the-wave (no atomics at all),
-//   k_cc_merge  unions only (i) a run that continues across a wave boundary with the wave before and (ii) vertical
-//               neighbours -- and skips a vertical edge whenever the edge one pixel to the left together with the two
-//               horizontal edges already implies it (in smooth regions that leaves one union per wave and row),
-//   k_cc_count  adds the LENGTH of each run to its root with one atomic per run instead of one per pixel (a large
-//               component no longer serialises on a single counter),
-//   k_cc_apply  erases the components that are small enough.
-struct CcPix {
-    int v;          // pixel value
-    bool valid;     // != newVal
-    bool cl;        // connected to the left neighbour (same row)
-};
+// Horizontal structure comes for free: inside a segment the pixels of a horizontal run (each connected to its left
+// neighbour) are found from one ballot.  Vertical structure inside a strip is carried in registers: a run takes the
+// label (= node id of a run start further up) of the first run above it that it touches, a run that touches nothing
+// above is "born" as the root of a new tree, and a global union is needed only where a run touches runs with
+// DIFFERENT labels.  In smooth regions that leaves no atomic at all inside a strip.
+//   k_cc_label    strip-local labelling; parent[run start] = label (plain store; born runs stay -1), count = 0 at
+//                 born runs (every root is one: all other nodes get a parent here), parent[segment's last pixel] =
+//                 its run start so that the neighbouring segment can name it
+//   k_cc_hborders / k_cc_vborders  unions across the strips' horizontal borders and the segments' vertical borders,
+//                 skipping every edge that the edge before it together with the two links along the border implies
+//   k_cc_count    per run start: root (read-only walk), parent[start] = root, run length added to count[root] --
+//                 accumulated down the strip while the root stays the same, and no longer added once the count
+//                 is past max_size (only `count <= max_size` is ever asked): big components cost a few atomics
+//   k_cc_apply    erases the runs whose root's count is small enough and puts parent back to -1
+constexpr int CC_ROWS = 16;
 
-__device__ __forceinline__ CcPix cc_load(const int16_t* __restrict__ row, int x, int w, int new_val, int max_diff)
-{
-    CcPix p;
-    p.v = x < w ? row[x] : new_val;
-    p.valid = p.v != new_val;
-    const int l = dpp_perm<DPP_WAVE_SHR1>((uint32_t)p.v);  // lane 0 is handled by the caller
-    p.cl = p.valid && l != new_val && abs(p.v - l) <= max_diff;
-    return p;
-}
-
-// lane of the first pixel of this lane's run inside the wave, and whether the run reaches back past lane 0
+// lane of the first pixel of this lane's run inside the segment
 __device__ __forceinline__ int cc_run_start(unsigned long long clmask, int lane)
 {
     const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
     const unsigned long long breaks = ~clmask & upto;  // lanes <= lane that do NOT connect to their left
     return breaks ? 63 - __clzll(breaks) : 0;
 }
-
-__global__ __launch_bounds__(256) void k_cc_rows(const int16_t* __restrict__ img, size_t pitch, size_t stride,
-                                                 int* parent, int w, int h, int new_val, int max_diff)
+// lane of its last pixel
+__device__ __forceinline__ int cc_run_end(unsigned long long clmask, int lane)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
-    img += (size_t)blockIdx.z * stride;
-    parent += (size_t)blockIdx.z * 2 * w * h;
-    CcPix p = cc_load(img + (size_t)y * pitch, x, w, new_val, max_diff);
-    if (lane == 0) p.cl = false;  // the link to the previous wave is an explicit union in k_cc_merge
-    const unsigned long long m = __ballot(p.cl);
-    if (x < w) {
-        const int i = y * w + x, start = cc_run_start(m, lane);
-        parent[i] = i - (lane - start);
-        // counts live at roots, and a root is always the first pixel of a run-in-the-wave (unions hook the larger
-        // root under the smaller, so roots stay among the initial ones): only those are zeroed
-        if (start == lane) parent[w * h + i] = 0;
+    const unsigned long long above = lane == 63 ? 0ull : (~clmask & (~0ull << (lane + 1)));
+    return above ? __ffsll((long long)above) - 2 : 63;
+}
+__device__ __forceinline__ bool cc_close(int a, int b, int new_val, int max_diff)
+{
+    return a != new_val && b != new_val && abs(a - b) <= max_diff;
+}
+// connected-to-the-left flag of a row held one pixel per lane (lane 0: never -- segments are joined by k_cc_borders)
+__device__ __forceinline__ bool cc_left(int v, int lane, int new_val, int max_diff)
+{
+    const int l = (int)dpp_perm<DPP_WAVE_SHR1>((uint32_t)v);
+    return lane != 0 && cc_close(v, l, new_val, max_diff);
+}
+
+#define CC_STRIP_PROLOGUE()                                                                          \
+    const int lane = threadIdx.x & 63;                                                               \
+    const int x = blockIdx.x * 256 + threadIdx.x;                                                    \
+    const int y0 = blockIdx.y * CC_ROWS, y1 = min(y0 + CC_ROWS, h);                                  \
+    img += (size_t)blockIdx.z * stride;                                                              \
+    parent += (size_t)blockIdx.z * 2 * w * h;                                                        \
+    if (blockIdx.x * 256 + (threadIdx.x & ~63) >= w) return; /* whole segment outside the image */
+
+__global__ __launch_bounds__(256) void k_cc_label(const int16_t* __restrict__ img, size_t pitch, size_t stride,
+                                                  int* parent, int w, int h, int new_val, int max_diff)
+{
+    CC_STRIP_PROLOGUE();
+    int* count = parent + w * h;
+    int v_up = new_val, lab_up = -1;
+    unsigned long long m_up = 0;
+    int v_next = x < w ? img[(size_t)y0 * pitch + x] : new_val;
+    for (int y = y0; y < y1; y++) {
+        const int v = v_next;
+        if (y + 1 < y1) v_next = x < w ? img[(size_t)(y + 1) * pitch + x] : new_val;
+        const bool valid = v != new_val;
+        const bool cl = cc_left(v, lane, new_val, max_diff);
+        const unsigned long long m = __ballot(cl);
+        const bool cu = cc_close(v, v_up, new_val, max_diff);
+        const unsigned long long mu = __ballot(cu);
+        const int start = cc_run_start(m, lane), end = cc_run_end(m, lane);
+        const unsigned long long runmask = (end == 63 ? ~0ull : ((2ull << end) - 1)) & (~0ull << start);
+        const unsigned long long cand = mu & runmask;  // pixels of this run that touch the row above
+        const int i = y * w + x, self = i - (lane - start);
+        int label = __shfl(lab_up, cand ? __ffsll((long long)cand) - 1 : lane);
+        if (!cand) label = self;
+        if (valid) {
+            if (lane == start) {
+                if (cand) parent[i] = label;
+                else count[i] = 0;
+            } else if (lane == 63) {
+                parent[i] = self;
+            }
+            if (cu && lab_up != label) {
+                // this run touches a second tree; one lane per overlap of the two runs reports it
+                const bool implied = lane > 0 && cl && ((mu >> (lane - 1)) & 1) && ((m_up >> lane) & 1);
+                if (!implied) uf_union(parent, lab_up, label);
+            }
+        }
+        v_up = v;
+        lab_up = valid ? label : -1;
+        m_up = m;
     }
 }
 
-__global__ __launch_bounds__(256) void k_cc_merge(const int16_t* __restrict__ img, size_t pitch, size_t stride,
-                                                  int* parent, int w, int h, int new_val, int max_diff)
+// horizontal border above strip (blockIdx.y + 1): 4 segments per block
+__global__ __launch_bounds__(256) void k_cc_hborders(const int16_t* __restrict__ img, size_t pitch, size_t stride,
+                                                     int* parent, int w, int h, int new_val, int max_diff)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     img += (size_t)blockIdx.z * stride;
     parent += (size_t)blockIdx.z * 2 * w * h;
-    const int16_t* row = img + (size_t)y * pitch;
-    CcPix p = cc_load(row, x, w, new_val, max_diff);
-    // the row below, same columns
-    int d = new_val;
-    if (y + 1 < h && x < w) d = row[pitch + x];
-    const bool cd = p.valid && d != new_val && abs(p.v - d) <= max_diff;         // vertical edge (x, y)-(x, y+1)
-    const int dl = dpp_perm<DPP_WAVE_SHR1>((uint32_t)d);
-    const bool cl_down = d != new_val && dl != new_val && abs(d - dl) <= max_diff;  // (x-1, y+1)-(x, y+1)
-    const bool cd_left = dpp_perm<DPP_WAVE_SHR1>((uint32_t)cd) != 0;              // vertical edge one pixel to the left
-    if (x >= w || !p.valid) return;
-    const int i = y * w + x;
-    if (lane == 0) {
-        // across the wave boundary: lane 0 has no DPP neighbour, so it looks at memory
-        if (x > 0) {
-            const int l = row[x - 1];
-            if (l != new_val && abs(p.v - l) <= max_diff) uf_union(parent, i, i - 1);
-        }
-        if (cd) uf_union(parent, i, i + w);
-    } else if (cd && !(p.cl && cd_left && cl_down)) {
-        uf_union(parent, i, i + w);
-    }
+    const int x = blockIdx.x * 256 + threadIdx.x, yd = (blockIdx.y + 1) * CC_ROWS, yu = yd - 1;
+    if (blockIdx.x * 256 + (threadIdx.x & ~63) >= w) return;
+    const int u = x < w ? img[(size_t)yu * pitch + x] : new_val;
+    const int d = x < w ? img[(size_t)yd * pitch + x] : new_val;
+    const bool clu = cc_left(u, lane, new_val, max_diff), cld = cc_left(d, lane, new_val, max_diff);
+    const unsigned long long mu = __ballot(clu), md = __ballot(cld);
+    const bool cv = cc_close(u, d, new_val, max_diff);
+    const bool cv_left = dpp_perm<DPP_WAVE_SHR1>((uint32_t)cv) != 0;
+    if (cv && !(lane > 0 && clu && cld && cv_left))
+        uf_union(parent, yu * w + x - (lane - cc_run_start(mu, lane)), yd * w + x - (lane - cc_run_start(md, lane)));
+}
+
+// vertical borders: a wave = 64 consecutive rows of the border left of segment sb >= 1 (lanes = rows); a = last pixel of
+// the segment to the left (a node: k_cc_label pointed it at its run start), b = first pixel of this segment (always a
+// run start)
+__global__ __launch_bounds__(256) void k_cc_vborders(const int16_t* __restrict__ img, size_t pitch, size_t stride,
+                                                     int* parent, int w, int h, int new_val, int max_diff, int nseg)
+{
+    const int lane = threadIdx.x & 63;
+    img += (size_t)blockIdx.z * stride;
+    parent += (size_t)blockIdx.z * 2 * w * h;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nrow64 = (h + 63) >> 6;
+    const int sb = 1 + wave / nrow64;
+    const int y = (wave % nrow64) * 64 + lane;
+    if (sb >= nseg) return;
+    const int xb = sb * 64;
+    const bool in = y < h;
+    const int a = in ? img[(size_t)y * pitch + xb - 1] : new_val;
+    const int b = in ? img[(size_t)y * pitch + xb] : new_val;
+    const bool ch = cc_close(a, b, new_val, max_diff);
+    const int a_up = (int)dpp_perm<DPP_WAVE_SHR1>((uint32_t)a), b_up = (int)dpp_perm<DPP_WAVE_SHR1>((uint32_t)b);
+    const bool ch_up = dpp_perm<DPP_WAVE_SHR1>((uint32_t)ch) != 0;
+    const bool implied = lane > 0 && ch_up && cc_close(a, a_up, new_val, max_diff) && cc_close(b, b_up, new_val, max_diff);
+    if (ch && !implied) uf_union(parent, y * w + xb - 1, y * w + xb);
 }
 
 __global__ __launch_bounds__(256) void k_cc_count(const int16_t* __restrict__ img, size_t pitch, size_t stride,
-                                                  int* parent, int w, int h, int new_val, int max_diff)
+                                                  int* parent, int w, int h, int new_val, int max_size, int max_diff)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
-    img += (size_t)blockIdx.z * stride;
-    parent += (size_t)blockIdx.z * 2 * w * h;
+    CC_STRIP_PROLOGUE();
     int* count = parent + w * h;
-    CcPix p = cc_load(img + (size_t)y * pitch, x, w, new_val, max_diff);
-    if (lane == 0) p.cl = false;
-    const unsigned long long m = __ballot(p.cl);
-    if (x >= w || !p.valid || p.cl) return;  // only the first pixel of a run-in-the-wave counts, for the whole run
-    const unsigned long long after = lane == 63 ? 0ull : (m >> (lane + 1));
-    const int len = 1 + (~after ? __ffsll((long long)~after) - 1 : 64);  // consecutive connected lanes behind it
-    const int i = y * w + x;
-    const int r = uf_find(parent, i);
-    parent[i] = r;
-    atomicAdd(&count[r], len);
+    int acc_root = -1, acc_n = 0;
+    auto flush = [&]() {
+        if (acc_n > 0 && __hip_atomic_load(&count[acc_root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= max_size)
+            atomicAdd(&count[acc_root], acc_n);
+    };
+    int v_next = x < w ? img[(size_t)y0 * pitch + x] : new_val;
+    for (int y = y0; y < y1; y++) {
+        const int v = v_next;
+        if (y + 1 < y1) v_next = x < w ? img[(size_t)(y + 1) * pitch + x] : new_val;
+        const unsigned long long m = __ballot(cc_left(v, lane, new_val, max_diff));
+        if (v != new_val && cc_run_start(m, lane) == lane) {  // one lane per run
+            const int i = y * w + x;
+            const int r = uf_find_ro(parent, i);
+            if (r != i) parent[i] = r;  // k_cc_apply reads the root in one step
+            const int len = cc_run_end(m, lane) - lane + 1;
+            if (r == acc_root) {
+                acc_n += len;
+            } else {
+                flush();
+                acc_root = r;
+                acc_n = len;
+            }
+        }
+    }
+    flush();
 }
 
-// one walk to the root per run-in-the-wave: its first pixel looks the component's size up, the others take its verdict
-__global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, size_t stride,
-                                                  const int* __restrict__ parent, int w, int h, int new_val,
-                                                  int max_size, int max_diff)
+__global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, size_t stride, int* parent, int w, int h,
+                                                  int new_val, int max_size, int max_diff)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
-    img += (size_t)blockIdx.z * stride;
-    parent += (size_t)blockIdx.z * 2 * w * h;
+    CC_STRIP_PROLOGUE();
     const int* count = parent + w * h;
-    CcPix p = cc_load(img + (size_t)y * pitch, x, w, new_val, max_diff);
-    if (lane == 0) p.cl = false;
-    const unsigned long long m = __ballot(p.cl);
-    const int start = cc_run_start(m, lane);
-    int kill = 0;
-    if (x < w && p.valid && start == lane) {
-        // first pixel of its run -> (compressed by k_cc_count) root; walk read-only
-        int r = y * w + x;
-        for (int q = parent[r]; q != r; q = parent[r]) r = q;
-        kill = count[r] <= max_size;
+    int v_next = x < w ? img[(size_t)y0 * pitch + x] : new_val;
+    for (int y = y0; y < y1; y++) {
+        const int v = v_next;
+        if (y + 1 < y1) v_next = x < w ? img[(size_t)(y + 1) * pitch + x] : new_val;
+        const bool valid = v != new_val;
+        const unsigned long long m = __ballot(cc_left(v, lane, new_val, max_diff));
+        const int start = cc_run_start(m, lane);
+        const int i = y * w + x;
+        int kill = 0;
+        if (valid && start == lane) {
+            const int p = parent[i];  // k_cc_count left the root here (-1: the run start is the root itself)
+            kill = count[p < 0 ? i : p] <= max_size;
+            if (p >= 0) parent[i] = -1;
+        } else if (valid && lane == 63) {
+            parent[i] = -1;
+        }
+        kill = __shfl(kill, start);
+        if (valid && kill) img[(size_t)y * pitch + x] = (int16_t)new_val;
     }
-    kill = __shfl(kill, start);
-    if (x < w && p.valid && kill) img[(size_t)y * pitch + x] = (int16_t)new_val;
 }
 
 size_t speckle_ws_bytes(int w, int h, int batch)
@@ -222,20 +302,31 @@ size_t speckle_ws_bytes(int w, int h, int batch)
     return (size_t)batch * w * h * 2 * sizeof(int);  // parent + count per image: the whole batch in one launch
 }
 
+// `clean` (may be NULL): in -- the workspace already holds -1 in every parent entry (a previous call on the same
+// workspace completed); out -- true once all four kernels are queued.  When it is not known to be clean it is cleared
+// first (memset to 0xFF: parent = -1; count is zeroed where it is used).
 int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, int new_val, int max_size,
-                   int max_diff, void* ws, int batch, hipStream_t st)
+                   int max_diff, void* ws, int batch, hipStream_t st, bool* clean)
 {
     if (!ws) { set_error("speckle workspace is NULL"); return CAMD_ERR_BAD_ARG; }
-    int n = w * h;
     int* parent = reinterpret_cast<int*>(ws);
-    dim3 grid(div_up(w, 256), h, batch);
-    (void)n;
-    hipLaunchKernelGGL(k_cc_rows, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
-    hipLaunchKernelGGL(k_cc_merge, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
-    hipLaunchKernelGGL(k_cc_count, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
+    if (!clean || !*clean) CAMD_HIP(hipMemsetAsync(ws, 0xFF, speckle_ws_bytes(w, h, batch), st));
+    if (clean) *clean = false;
+    const int nseg = div_up(w, 64), nstrips = div_up(h, CC_ROWS), hblocks = div_up(w, 256);
+    const int vwaves = (nseg - 1) * div_up(h, 64);
+    dim3 grid(hblocks, nstrips, batch);
+    hipLaunchKernelGGL(k_cc_label, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_diff);
+    if (nstrips > 1)
+        hipLaunchKernelGGL(k_cc_hborders, dim3(hblocks, nstrips - 1, batch), dim3(256), 0, st, img, pitch_e, stride_e,
+                           parent, w, h, new_val, max_diff);
+    if (vwaves > 0)
+        hipLaunchKernelGGL(k_cc_vborders, dim3(div_up(vwaves, 4), 1, batch), dim3(256), 0, st, img, pitch_e, stride_e,
+                           parent, w, h, new_val, max_diff, nseg);
+    hipLaunchKernelGGL(k_cc_count, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_size, max_diff);
     hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), 0, st, img, pitch_e, stride_e, parent, w, h, new_val, max_size,
                        max_diff);
     CAMD_LAUNCH_CHECK();
+    if (clean) *clean = true;
     return CAMD_OK;
 }
 
@@ -264,7 +355,7 @@ int camd_filter_speckles_s16(int16_t* img, int w, int h, int new_val, int max_sp
         return CAMD_ERR_BAD_ARG;
     }
     return launch_speckle(img, w, (size_t)w * h, w, h, new_val, max_speckle_size, max_diff, labels_ws, batch,
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, nullptr);  // a caller's scratch: nothing is known about its contents
 }
 
 }  // extern "C"

@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void k_gather_stripes(const int16_t* __restric
 int launch_median3(const int16_t* src, size_t src_pitch_e, size_t src_stride_e, int16_t* dst,
                    size_t dst_pitch_e, size_t dst_stride_e, int w, int h, int batch, hipStream_t st);
 int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, int new_val, int max_size,
-                   int max_diff, void* ws, int batch, hipStream_t st);
+                   int max_diff, void* ws, int batch, hipStream_t st, bool* clean);
 size_t speckle_ws_bytes(int w, int h, int batch);
 
 // ------------------------------------------------------------------------------------------------
@@ -734,6 +734,7 @@ struct camd_sgbm {
     uint16_t *C, *S;      // S doubles as the hsum buffer before aggregation
     int16_t* raw;         // [max_batch][H][W] disparity before median
     void* speckle_ws;
+    bool speckle_clean;   // every parent entry of speckle_ws is -1 (post.hip keeps it so from call to call)
     // band-wavefront path (sgbm_band.hpp)
     bool band_ok;         // geometry supported by k_band instantiations
     int path;             // 0 = band passes (default when band_ok), 1 = one k_scan per direction
@@ -1615,7 +1616,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         if (rc != CAMD_OK) return rc;
         if (g.speckleWindowSize > 0) {
             rc = launch_speckle(disp, dpe, dse, g.W, g.H, (g.minD - 1) * 16, g.speckleWindowSize,
-                                16 * g.speckleRange, h->speckle_ws, batch, st);
+                                16 * g.speckleRange, h->speckle_ws, batch, st, &h->speckle_clean);
             if (rc != CAMD_OK) return rc;
         }
     }

@@ -247,6 +247,76 @@ def fuzz_pipeline(n, seed=11, log=print):
                 within_tolerance_but_not_bit_identical=inexact_total)
 
 
+def speckle_image(rng, kind, h, w, new_val):
+    """Disparity-like int16 images for the speckle filter: smooth regions with noise and holes, few-level noise (many
+    tiny components), one-pixel-wide serpentines (a long component through many strips and segments) and combs (teeth
+    that only meet at the bottom: every tooth is born as its own tree and merged late)."""
+    if kind == 0:
+        yy, xx = np.mgrid[:h, :w]
+        img = (16 * 20 + 3 * xx + 5 * yy).astype(np.int16)
+        for _ in range(int(rng.integers(1, 5))):
+            y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+            img[y0:y0 + int(rng.integers(1, h + 1)), x0:x0 + int(rng.integers(1, w + 1))] += np.int16(rng.integers(-400, 400))
+        spk = rng.random((h, w)) < 0.03
+        img[spk] = (rng.integers(0, 100, int(spk.sum())) * 16).astype(np.int16)
+        img[rng.random((h, w)) < 0.05] = new_val
+    elif kind == 1:
+        img = (rng.integers(0, int(rng.integers(2, 6)), (h, w)) * 40).astype(np.int16)
+        img[rng.random((h, w)) < 0.2] = new_val
+    elif kind == 2:
+        tr = rng.random() < 0.5  # (vertical serpentine: built lying down, then transposed)
+        hh, ww = (w, h) if tr else (h, w)
+        img = np.full((hh, ww), new_val, np.int16)
+        step = int(rng.integers(2, 5))
+        for r, y in enumerate(range(0, hh, step)):
+            img[y, :] = 500
+            img[y:min(y + step, hh), ww - 1 if r % 2 == 0 else 0] = 500  # connector alternately right / left
+        if tr:
+            img = np.ascontiguousarray(img.T)
+    else:
+        img = np.full((h, w), new_val, np.int16)
+        pitch = int(rng.integers(2, 7))
+        img[:, ::pitch] = 300
+        img[h - 1 if rng.random() < 0.5 else 0, :] = 300
+        if rng.random() < 0.3:
+            img[(np.indices((h, w)).sum(0) % 2 == 0) & (img == new_val)] = 1000
+    return img
+
+
+def fuzz_speckle(n, seed=9, log=print):
+    """camd_filter_speckles_s16 against oracle.filter_speckles_s16 (= cv2.filterSpeckles' flood fill): sizes around the
+    64-column segments and 16-row strips of the kernels, batches, thresholds from 0 to "everything", and -- through one
+    StereoSGBM handle used for several different pairs -- the handle-owned workspace that is never re-initialised."""
+    import oracle
+    from calibrating_amd import imgproc
+    rng = np.random.default_rng(seed)
+    br, bad = {}, []
+    for case in range(n):
+        kind = case % 4
+        h = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 48, 70, 130]))
+        w = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 200, 256, 257, 300, 520]))
+        new_val = int(rng.choice([-16, 16, 0]))
+        nb = int(rng.choice([1, 1, 2, 5]))
+        imgs = np.stack([speckle_image(rng, kind, h, w, new_val) for _ in range(nb)])
+        max_size = int(rng.choice([0, 1, 5, 40, 200, 5000, h * w]))
+        max_diff = int(rng.choice([0, 16, 32, 200]))
+        got = imgproc.filterSpeckles(imgs if nb > 1 else imgs[0], new_val, max_size, max_diff)
+        got = got if nb > 1 else got[None]
+        _count(br, ("smooth", "noise", "serpentine", "comb")[kind])
+        if nb > 1:
+            _count(br, "batched")
+        for i in range(nb):
+            want = oracle.filter_speckles_s16(imgs[i], new_val, max_size, max_diff)
+            if (want != imgs[i]).any():
+                _count(br, "images_with_erased_pixels")
+            if not np.array_equal(got[i], want):
+                bad.append(dict(case=case, kind=kind, shape=(h, w), image="%d/%d" % (i, nb), new_val=new_val,
+                                max_size=max_size, max_diff=max_diff, pixels=int((got[i] != want).sum())))
+                log("MISMATCH", bad[-1])
+                break
+    return dict(fuzzer="speckle", seed=seed, cases=n, branches=br, mismatches=bad)
+
+
 def report(res, log=print):
     """One greppable summary line per run (what profiles/*_fuzz_*.log keep)."""
     st = stamp()

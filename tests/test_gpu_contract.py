@@ -78,7 +78,7 @@ class _PostFilteringSGBM(ca.SemiGlobalBlockMatching):
     def __call__(self, img1, img2):
         disparity = super().__call__(img1, img2)
         assert isinstance(disparity, np.ndarray), "the plugin contract is NumPy in, NumPy out"
-        disparity[disparity > 40] = 0
+        disparity[disparity > 15] = 0
         return dict(disparity=disparity, filtered_by="subclass")
 
 
@@ -96,8 +96,8 @@ def test_sgbm_subclass_override_is_honoured(oracle, max_size):
     assert got["filtered_by"] == "subclass"
     r1, r2, mask = rectified_pair(oracle, stereo, img1, img2)
     want = matcher_disparity(oracle, cfg, r1, r2)
-    assert (want > 40).any() and (want > 0).mean() > 0.5
-    want[want > 40] = 0
+    assert (want > 15).mean() > 0.1 and (want > 0).mean() > 0.5
+    want[want > 15] = 0
     assert np.array_equal(got["disparity"], mask * want)
     with pytest.raises(ValueError, match="own __call__"):
         stereo.get_depth_batch(np.stack([img1, img1]), np.stack([img2, img2]))
