@@ -40,10 +40,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 CLOCK_HZ, N_CUS = 2.4e9, 256  # MI355X peak engine clock and CUs: one VALU wave-instruction per CU and cycle (4 SIMD16s)
 
 
-def _latest_profile(pattern):
-    """The committed rocprofv3 --pmc summary of the most recent round that has one (profiles/rNN_<pattern>)."""
+def _latest_profile(pattern, pairs_per_launch=None, exclude=None):
+    """The committed rocprofv3 --pmc summary of the most recent round that has one (profiles/rNN_<pattern>); with
+    `pairs_per_launch`, the most recent one taken at exactly that many pairs per launch is preferred (per-pair traffic
+    depends a little on it: the band passes' edge records and tails)."""
     import glob
-    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    hits = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern))
+                  if not (exclude and exclude in os.path.basename(f)))
+    if pairs_per_launch is not None:
+        same = []
+        for f in hits:
+            try:
+                if json.load(open(f)).get("pairs_per_launch") == pairs_per_launch:
+                    same.append(f)
+            except Exception:
+                pass
+        hits = same or hits
     return os.path.relpath(hits[-1], ROOT) if hits else None
 
 
@@ -108,7 +120,8 @@ def stage_table(V, HW, cn, mode):
         "scan": ("k_band first pass (4 directions: C in, S out)", 2 * V, ("k_band", ", true, 0,")),
         "scan_last": (last, 2 * V, ("k_band", ", 2,")),
         "wta": ("k_lrcheck", 12 * HW, ("k_lrcheck",)),
-        "median_speckle": ("k_median3", 4 * HW, ("k_median3",)),
+        "median": ("k_median3", 4 * HW, ("k_median3",)),
+        "speckle": ("k_cc_* (filterSpeckles: label, borders, count, apply)", 4 * HW, ("k_cc_",)),
     }
 
 
@@ -377,18 +390,79 @@ def config_c4(ca, synthetic, dev, nb=16, reps=3):
                 achieved_GBs=b_alg * rate / 1e9, frac=b_alg * rate / 1e9 / HBM_PEAK_GBS)
 
 
-def config_c5(ca, synthetic, dev, streams, nb=128):
+def depth_path_stages(st, imgs1, imgs2, W, H, D, cn, reps=5):
+    """Per-stage GPU time of one Stereo.get_depth_batch call (each stage alone on the GPU, torch events on the current
+    stream, which is the stream the library launches on; the SGBM kernels from the library's own hipEvent brackets), with
+    each stage's algorithmic HBM bytes per pair and the fraction of the HBM peak it reaches."""
+    import torch
+    sm = st.stereo_matching
+    sg = sm.stereo_sgbm
+    nb, HW = imgs1.shape[0], W * H
+    _, V = algorithmic_bytes_per_pair(W, H, D, cn)
+
+    def timed(fn):
+        out = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, out
+
+    rows = []  # (stage, ms per call, algorithmic bytes per pair)
+    ms, (r1, r2) = timed(lambda: st.rectify(imgs1, imgs2))
+    rows.append(("rectify x2 (k_remap_f32 Lanczos-4, right image translated)", ms, 4 * HW * cn))
+    sg.compute(r1, r2)
+    sg.set_profiling(True)
+    acc = {}
+    for _ in range(reps):
+        disp16 = sg.compute(r1, r2)
+        for k, v in sg.stage_times_ms().items():
+            acc[k] = acc.get(k, 0.0) + v / reps
+    sg.set_profiling(False)
+    table = stage_table(V, HW, cn, "sgbm")
+    for k, v in acc.items():
+        if k in table and v >= 0.002:
+            rows.append(("SGBM " + table[k][0], v, table[k][1]))
+    tb = st._tables(imgs1.device)
+    ms, (_, depth) = timed(lambda: st._fused_depth(sm, disp16, tb))
+    rows.append(("disp_to_depth (k_disp_to_depth: int16 -> f32 disparity + f64 depth)", ms, 14 * HW))
+    ms, _ = timed(lambda: st.unrectify_depth(depth))
+    rows.append(("unrectify_depth (k_unrectify: f64 gather)", ms, 16 * HW))
+    ms, _ = timed(lambda: st.undistort_img(imgs1))
+    rows.append(("undistort_img1 (k_remap_fixed_bilinear)", ms, 2 * HW * cn))
+    total = sum(r[1] for r in rows)
+    return {"pairs_per_call": nb, "sum_ms_per_call": total,
+            "stages": [{"stage": n, "ms_per_call": m, "share": m / total, "algorithmic_bytes_per_pair": b,
+                        "hbm_frac": b * nb / (m * 1e-3) / 1e9 / HBM_PEAK_GBS} for n, m, b in rows]}
+
+
+def config_c5(ca, synthetic, dev, streams, nb=256):
     """BASELINE.json configs[4]: 640x480 RGB, D=64, LR check on, speckle 100 / 2, the FULL get_depth path, batched."""
     import torch
     W, H, D = 640, 480, 64
     P = dict(minDisparity=0, numDisparities=D, blockSize=5, P1=8 * 3 * 25, P2=32 * 3 * 25, disp12MaxDiff=1, preFilterCap=0,
              uniquenessRatio=10, speckleWindowSize=100, speckleRange=2, mode=0)
     pairs = [synthetic.scene_pair(100 + i, W, H, 3) for i in range(8)]
-    B1 = torch.from_numpy(np.stack([pairs[i % 8][0] for i in range(nb)])).to(dev)
-    B2 = torch.from_numpy(np.stack([pairs[i % 8][1] for i in range(nb)])).to(dev)
+
+    def batch(n):
+        return (torch.from_numpy(np.stack([pairs[i % 8][0] for i in range(n)])).to(dev),
+                torch.from_numpy(np.stack([pairs[i % 8][1] for i in range(n)])).to(dev))
+    B1, B2 = batch(nb)
     r = depth_path_rate(ca, synthetic, P, B1, B2, streams, W, H, D, 3, max_depth=3.5, reps=6)
     r["workload"] = ("640x480 RGB pairs through the whole get_depth path (rectify x2, SGBM numDisparities=64 blockSize=5 "
                      "LR check on speckle 100/2, disp_to_depth, unrectify, undistort), %d pairs per call" % nb)
+    st = ca.Stereo.load(synthetic.rig(W, H))
+    st.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(P, max_size=max(W, H))), max_depth=3.5)
+    r["per_stage"] = depth_path_stages(st, B1, B2, W, H, D, 3)
+    del B1, B2
+    # the same with 128 pairs per call (what rounds 2 and 3 reported): an image this small needs a deep batch to fill the
+    # band passes' last round of workgroups (9 bands x pairs over 512 places)
+    b1, b2 = batch(128)
+    r128 = depth_path_rate(ca, synthetic, P, b1, b2, streams, W, H, D, 3, max_depth=3.5, reps=6)
+    r["at_128_pairs_per_call"] = {k: r128[k] for k in ("pairs_per_s", "single_stream_pairs_per_s", "frac")}
     return r
 
 
@@ -610,8 +684,11 @@ def main():
         gpu_ms_step = agg["seconds"] / a.steps * 1e3             # the timed region (batches in flight overlap)
         # HBM traffic per kernel from the committed PMC profile of the same kernels (separate rocprofv3 --pmc
         # passes, 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction); null when no profile matches this workload
-        pmc_rel = _latest_profile("pmc_traffic%s.json" % ("_hh" if a.mode == "hh" else ""))
-        sq_rel = _latest_profile("pmc_sq%s.json" % ("_hh" if a.mode == "hh" else ""))
+        suffix = "_hh" if a.mode == "hh" else ""
+        # (rNN_pmc_traffic[_hh][_b<pairs per launch>].json; the one taken at this run's pairs per launch is preferred)
+        pmc_rel = _latest_profile("pmc_traffic%s*.json" % suffix, nb, exclude=None if suffix else "_hh")
+        pmc_other = _latest_profile("pmc_traffic%s.json" % suffix)
+        sq_rel = _latest_profile("pmc_sq%s.json" % suffix)
         pmc = sq = None
         if a.channels == 3 and (a.width, a.height, a.disparities, a.block) == (1920, 1080, 128, 5):
             pmc = json.load(open(os.path.join(ROOT, pmc_rel))) if pmc_rel else None
@@ -658,6 +735,13 @@ def main():
         # whole-step traffic = every kernel of the committed PMC profile (incl. the small init / check kernels)
         traffic_total = sum(v["hbm_bytes_per_pair"] for v in pmc["kernels"].values()) * nb if pmc else None
         achieved = b_alg * nb / (gpu_ms_step * 1e-3) / 1e9
+        # the same ratio from the profile taken at another number of pairs per launch, when it differs by more than 2 %
+        other_ratio = None
+        if pmc and pmc_other and pmc_other != pmc_rel:
+            po = json.load(open(os.path.join(ROOT, pmc_other)))
+            ro = sum(v["hbm_bytes_per_pair"] for v in po["kernels"].values()) / b_alg
+            if abs(ro / (traffic_total / (b_alg * nb)) - 1) > 0.02:
+                other_ratio = {"profile": pmc_other, "pairs_per_launch": po.get("pairs_per_launch"), "traffic_ratio": ro}
         line = {
             "metric": "stereo pairs/s at 1920x1080 numDisparities=128",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -682,7 +766,9 @@ def main():
                 "gpu_ms_per_step": gpu_ms_step, "kernel_ms_per_step": kernel_ms_step,
                 "traffic": traffic_total,
                 "traffic_ratio": (traffic_total / (b_alg * nb)) if traffic_total else None,
-                "traffic_source": (pmc_rel + " (bytes per pair per launch x pairs per launch)") if pmc else None,
+                "traffic_source": (pmc_rel + " (bytes per pair per launch x pairs per launch; profile taken at %s pairs per "
+                                             "launch)" % pmc.get("pairs_per_launch")) if pmc else None,
+                "traffic_ratio_other_profile": other_ratio,
                 "valu_source": (sq_rel + " (SQ_INSTS_VALU per pair x pairs per launch / (%d CUs x %.1f GHz) / this run's "
                                          "kernel time)" % (N_CUS, CLOCK_HZ / 1e9)) if sq else None,
                 "dominant_kernel": dict(kernels[dom], stage=dom) if dom else None,

@@ -183,6 +183,14 @@ __device__ __forceinline__ uint32_t group_min_dup16(uint32_t pk)
     return group_min_u32_full<LANES>(v);              // x * 0x10001 is monotonic in x
 }
 
+// The int16 regime the SGBM kernels implement: camd_sgbm_create refuses parameters beyond these (normalise() in
+// sgbm.hip), and the kernels' carry-free 32-bit arithmetic on packed 16-bit pairs is proved against the same numbers
+// (sgm_step's + P1 / + P2, NOCARRY in sgbm_cost.hpp) -- one definition, so a raised limit cannot leave a stale proof.
+constexpr int CAMD_MAX_P2 = 24000;
+constexpr int CAMD_MAX_FTZERO = 127;
+static_assert(CAMD_MAX_P2 < 0x8000, "P1 < P2 must fit a signed 16-bit half: sgm_step adds them with plain 32-bit adds");
+static_assert(2 * CAMD_MAX_FTZERO + 63 < 0x8000, "a pixel cost must fit a 16-bit half");
+
 static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace camd

@@ -145,13 +145,43 @@ __device__ __forceinline__ bool cc_left(int v, int lane, int new_val, int max_di
     return lane != 0 && cc_close(v, l, new_val, max_diff);
 }
 
+// Every strip kernel starts the same way: all CC_ROWS rows of the segment are requested at once (a wave walking its
+// rows one load at a time spends the pass waiting: 16 dependent round trips), rows below the image read as new_val.
 #define CC_STRIP_PROLOGUE()                                                                          \
     const int lane = threadIdx.x & 63;                                                               \
     const int x = blockIdx.x * 256 + threadIdx.x;                                                    \
-    const int y0 = blockIdx.y * CC_ROWS, y1 = min(y0 + CC_ROWS, h);                                  \
+    const int y0 = blockIdx.y * CC_ROWS;                                                             \
     img += (size_t)blockIdx.z * stride;                                                              \
     parent += (size_t)blockIdx.z * 2 * w * h;                                                        \
-    if (blockIdx.x * 256 + (threadIdx.x & ~63) >= w) return; /* whole segment outside the image */
+    if (blockIdx.x * 256 + (threadIdx.x & ~63) >= w) return; /* whole segment outside the image */   \
+    int vrow[CC_ROWS];                                                                               \
+    _Pragma("unroll") for (int k = 0; k < CC_ROWS; k++)                                              \
+        vrow[k] = (x < w && y0 + k < h) ? img[(size_t)(y0 + k) * pitch + x] : new_val;
+
+// What a strip kernel knows about the run of its lane in the current row
+struct CcRun {
+    bool valid;                // pixel != newVal
+    int start, end;            // lanes of the run's first / last pixel
+    unsigned long long m;      // connected-to-the-left mask of the row
+    unsigned long long cand;   // pixels of this run that touch the row above (inside the strip)
+    int first;                 // lane of the first of them (own lane if none)
+    bool stored;               // k_cc_label stores a parent entry for this run's start: its run is born (then the entry is
+                               // the union-find's), or another segment / strip may have to name it
+};
+__device__ __forceinline__ CcRun cc_run(int v, int v_up, int lane, bool last_row, int new_val, int max_diff)
+{
+    CcRun r;
+    r.valid = v != new_val;
+    r.m = __ballot(cc_left(v, lane, new_val, max_diff));
+    const unsigned long long mu = __ballot(cc_close(v, v_up, new_val, max_diff));
+    r.start = cc_run_start(r.m, lane);
+    r.end = cc_run_end(r.m, lane);
+    const unsigned long long runmask = (r.end == 63 ? ~0ull : ((2ull << r.end) - 1)) & (~0ull << r.start);
+    r.cand = mu & runmask;
+    r.first = r.cand ? __ffsll((long long)r.cand) - 1 : lane;
+    r.stored = !r.cand || r.start == 0 || r.end == 63 || last_row;
+    return r;
+}
 
 __global__ __launch_bounds__(256) void k_cc_label(const int16_t* __restrict__ img, size_t pitch, size_t stride,
                                                   int* parent, int w, int h, int new_val, int max_diff)
@@ -160,37 +190,31 @@ __global__ __launch_bounds__(256) void k_cc_label(const int16_t* __restrict__ im
     int* count = parent + w * h;
     int v_up = new_val, lab_up = -1;
     unsigned long long m_up = 0;
-    int v_next = x < w ? img[(size_t)y0 * pitch + x] : new_val;
-    for (int y = y0; y < y1; y++) {
-        const int v = v_next;
-        if (y + 1 < y1) v_next = x < w ? img[(size_t)(y + 1) * pitch + x] : new_val;
-        const bool valid = v != new_val;
-        const bool cl = cc_left(v, lane, new_val, max_diff);
-        const unsigned long long m = __ballot(cl);
-        const bool cu = cc_close(v, v_up, new_val, max_diff);
-        const unsigned long long mu = __ballot(cu);
-        const int start = cc_run_start(m, lane), end = cc_run_end(m, lane);
-        const unsigned long long runmask = (end == 63 ? ~0ull : ((2ull << end) - 1)) & (~0ull << start);
-        const unsigned long long cand = mu & runmask;  // pixels of this run that touch the row above
-        const int i = y * w + x, self = i - (lane - start);
-        int label = __shfl(lab_up, cand ? __ffsll((long long)cand) - 1 : lane);
-        if (!cand) label = self;
-        if (valid) {
-            if (lane == start) {
-                if (cand) parent[i] = label;
-                else count[i] = 0;
+#pragma unroll
+    for (int k = 0; k < CC_ROWS; k++) {
+        const int y = y0 + k, v = vrow[k];
+        if (y >= h) break;
+        const CcRun r = cc_run(v, v_up, lane, k == CC_ROWS - 1, new_val, max_diff);
+        const int i = y * w + x, self = i - (lane - r.start);
+        int label = __shfl(lab_up, r.first);
+        if (!r.cand) label = self;
+        if (r.valid) {
+            if (lane == r.start) {
+                if (!r.cand) count[i] = 0;
+                else if (r.stored) parent[i] = label;
             } else if (lane == 63) {
                 parent[i] = self;
             }
+            const bool cu = (r.cand >> lane) & 1;
             if (cu && lab_up != label) {
                 // this run touches a second tree; one lane per overlap of the two runs reports it
-                const bool implied = lane > 0 && cl && ((mu >> (lane - 1)) & 1) && ((m_up >> lane) & 1);
+                const bool implied = lane > 0 && ((r.m >> lane) & 1) && ((r.cand >> (lane - 1)) & 1) && ((m_up >> lane) & 1);
                 if (!implied) uf_union(parent, lab_up, label);
             }
         }
         v_up = v;
-        lab_up = valid ? label : -1;
-        m_up = m;
+        lab_up = r.valid ? label : -1;
+        m_up = r.m;
     }
 }
 
@@ -248,24 +272,33 @@ __global__ __launch_bounds__(256) void k_cc_count(const int16_t* __restrict__ im
         if (acc_n > 0 && __hip_atomic_load(&count[acc_root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= max_size)
             atomicAdd(&count[acc_root], acc_n);
     };
-    int v_next = x < w ? img[(size_t)y0 * pitch + x] : new_val;
-    for (int y = y0; y < y1; y++) {
-        const int v = v_next;
-        if (y + 1 < y1) v_next = x < w ? img[(size_t)(y + 1) * pitch + x] : new_val;
-        const unsigned long long m = __ballot(cc_left(v, lane, new_val, max_diff));
-        if (v != new_val && cc_run_start(m, lane) == lane) {  // one lane per run
-            const int i = y * w + x;
-            const int r = uf_find_ro(parent, i);
-            if (r != i) parent[i] = r;  // k_cc_apply reads the root in one step
-            const int len = cc_run_end(m, lane) - lane + 1;
-            if (r == acc_root) {
+    int v_up = new_val, root_up = -1;
+#pragma unroll
+    for (int k = 0; k < CC_ROWS; k++) {
+        const int y = y0 + k, v = vrow[k];
+        if (y >= h) break;
+        const CcRun r = cc_run(v, v_up, lane, k == CC_ROWS - 1, new_val, max_diff);
+        const int i = y * w + x;
+        // a run that touches the row above has that run's root (all unions are done); only a born run walks
+        int root = __shfl(root_up, r.first);
+        if (r.valid && !r.cand && lane == r.start) {
+            root = uf_find_ro(parent, i);
+            if (root != i) parent[i] = root;  // k_cc_apply reads the root in one step
+        }
+        const int born_root = __shfl(root, r.start);
+        if (!r.cand) root = born_root;
+        if (r.valid && lane == r.start) {  // one lane per run
+            const int len = r.end - lane + 1;
+            if (root == acc_root) {
                 acc_n += len;
             } else {
                 flush();
-                acc_root = r;
+                acc_root = root;
                 acc_n = len;
             }
         }
+        v_up = v;
+        root_up = r.valid ? root : -1;
     }
     flush();
 }
@@ -275,24 +308,30 @@ __global__ __launch_bounds__(256) void k_cc_apply(int16_t* img, size_t pitch, si
 {
     CC_STRIP_PROLOGUE();
     const int* count = parent + w * h;
-    int v_next = x < w ? img[(size_t)y0 * pitch + x] : new_val;
-    for (int y = y0; y < y1; y++) {
-        const int v = v_next;
-        if (y + 1 < y1) v_next = x < w ? img[(size_t)(y + 1) * pitch + x] : new_val;
-        const bool valid = v != new_val;
-        const unsigned long long m = __ballot(cc_left(v, lane, new_val, max_diff));
-        const int start = cc_run_start(m, lane);
+    int v_up = new_val, kill_up = 0;
+#pragma unroll
+    for (int k = 0; k < CC_ROWS; k++) {
+        const int y = y0 + k, v = vrow[k];
+        if (y >= h) break;
+        const CcRun r = cc_run(v, v_up, lane, k == CC_ROWS - 1, new_val, max_diff);
         const int i = y * w + x;
-        int kill = 0;
-        if (valid && start == lane) {
-            const int p = parent[i];  // k_cc_count left the root here (-1: the run start is the root itself)
-            kill = count[p < 0 ? i : p] <= max_size;
-            if (p >= 0) parent[i] = -1;
-        } else if (valid && lane == 63) {
+        int kill = __shfl(kill_up, r.first);  // the verdict of the run above, if there is one
+        if (r.valid && lane == r.start) {
+            if (!r.cand) {
+                const int p = parent[i];  // k_cc_count left the root here (-1: this run start is the root itself)
+                kill = count[p < 0 ? i : p] <= max_size;
+                if (p >= 0) parent[i] = -1;
+            } else if (r.stored) {
+                parent[i] = -1;
+            }
+        } else if (r.valid && lane == 63) {
             parent[i] = -1;
         }
-        kill = __shfl(kill, start);
-        if (valid && kill) img[(size_t)y * pitch + x] = (int16_t)new_val;
+        const int born_kill = __shfl(kill, r.start);
+        if (!r.cand) kill = born_kill;
+        if (r.valid && kill) img[(size_t)y * pitch + x] = (int16_t)new_val;
+        v_up = v;
+        kill_up = r.valid ? kill : 0;
     }
 }
 

@@ -687,13 +687,17 @@ namespace camd {
 __global__ __launch_bounds__(256) void k_gather_stripes(const int16_t* __restrict__ rawv, size_t rawv_stride_e,
                                                         int16_t* __restrict__ raw, size_t raw_stride_e, int W, int H,
                                                         int stripe_sz, CostRanges cr, const uint32_t* __restrict__ err,
-                                                        int invalid)
+                                                        const uint32_t* __restrict__ refused, int invalid)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, pair = blockIdx.z;
     if (x >= W) return;
     const int s = min(y / stripe_sz, cr.n - 1);
-    // a band pass that gave up waiting (sgbm_band.hpp) must not hand back plausible garbage: like k_lrcheck
-    const bool bad = err && *err;
+    // a band pass that gave up waiting (sgbm_band.hpp) must not hand back plausible garbage: like k_lrcheck (bit 0 of
+    // the error word); and a pair with ANY refused stripe (`refused`: the per-volume below-P2 flags, passed only when
+    // there is no exact path to redo them) is invalid as a whole, as the header promises -- not just that stripe's rows
+    bool bad = err && (*err & 1u);
+    if (refused)
+        for (int k = 0; k < cr.n; k++) bad |= refused[pair * cr.n + k] != 0;
     raw[(size_t)pair * raw_stride_e + (size_t)y * W + x] =
         bad ? (int16_t)invalid : rawv[(size_t)(pair * cr.n + s) * rawv_stride_e + (size_t)(y - cr.start[s]) * W + x];
 }
@@ -709,10 +713,10 @@ size_t speckle_ws_bytes(int w, int h, int batch);
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-enum Stage { ST_COST = 0, ST_HSUM, ST_VSUM, ST_SCAN, ST_SCAN2, ST_WTA, ST_POST, ST_COUNT };
+enum Stage { ST_COST = 0, ST_HSUM, ST_VSUM, ST_SCAN, ST_SCAN2, ST_WTA, ST_POST, ST_SPECKLE, ST_COUNT };
 // "cost" = the fused cost kernel (then hsum / vsum are empty), "hsum" + "vsum" = the split pair (then cost is empty);
 // "scan" = the aggregation launches; on the band path the last pass is timed separately as "scan_last"
-static const char* kStageNames[ST_COUNT] = {"cost", "hsum", "vsum", "scan", "scan_last", "wta", "median_speckle"};
+static const char* kStageNames[ST_COUNT] = {"cost", "hsum", "vsum", "scan", "scan_last", "wta", "median", "speckle"};
 
 }  // namespace camd
 
@@ -797,7 +801,7 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
     }
     // (P2: cv2's rule of thumb 32 * cn * blockSize^2 is 21600 at block 15 RGB; the fuzz covers the range up to the
     // limit -- in the last few per cent below 32767 the exact int path meets narrowings it does not restate)
-    if (g->P2 > 24000 || g->ftzero > 127) {
+    if (g->P2 > CAMD_MAX_P2 || g->ftzero > CAMD_MAX_FTZERO) {
         set_error("P2 = %d / preFilterCap = %d outside the int16 regime the kernels implement", g->P2,
                   p->preFilterCap);
         return CAMD_ERR_UNSUPPORTED;
@@ -1268,7 +1272,19 @@ int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
     else if (option == CAMD_OPT_COST && value >= CAMD_COST_AUTO && value <= CAMD_COST_SPLIT) h->cost_path = value;
     else if (option == CAMD_OPT_SATURATE) h->saturate = value != 0;
     else if (option == CAMD_OPT_3WAY_SIMD_LANES && (value == 1 || value == 8)) h->way3_simd_lanes = value;
-    else if (option == CAMD_OPT_EXACT) h->exact_cap = (value != 0 && h->Lx) ? 1 : 0;
+    else if (option == CAMD_OPT_EXACT) {
+        if (value != 0 && !h->Lx && h->may_overflow) {
+            // the workspace could not be had when the handle was made: try again rather than stay in refuse mode silently
+            if (hipMalloc((void**)&h->Lx, (size_t)h->g.npaths * h->vol_elems * 4) != hipSuccess) {
+                (void)hipGetLastError();
+                h->Lx = nullptr;
+                set_error("no memory for the exact path's %d per-direction int volumes; the handle keeps refusing flagged pairs",
+                          h->g.npaths);
+                return CAMD_ERR_NOMEM;
+            }
+        }
+        h->exact_cap = (value != 0 && h->Lx) ? 1 : 0;
+    }
     else { set_error("unknown option %d / value %d", option, value); return CAMD_ERR_BAD_ARG; }
     return CAMD_OK;
 }
@@ -1596,7 +1612,8 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
             if (rc != CAMD_OK) return rc;
         }
         hipLaunchKernelGGL(k_gather_stripes, dim3(div_up(g.W, 256), g.H, batch), dim3(256), 0, st, h->rawv, rawv_stride,
-                           h->raw, raw_stride, g.W, g.H, h->stripe_sz, h->cr, band ? h->err : nullptr, (g.minD - 1) * 16);
+                           h->raw, raw_stride, g.W, g.H, h->stripe_sz, h->cr, band ? h->err : nullptr,
+                           (may_overflow && !h->exact_cap) ? h->cost_neg : nullptr, (g.minD - 1) * 16);
         CAMD_LAUNCH_CHECK();
         if (band) CAMD_HIP(hipMemcpyAsync(h->err_host, h->err, 4, hipMemcpyDeviceToHost, st));
     } else {
@@ -1614,6 +1631,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     {
         int rc = launch_median3(h->raw, g.W, raw_stride, disp, dpe, dse, g.W, g.H, batch, st);
         if (rc != CAMD_OK) return rc;
+        MARK(ST_SPECKLE);
         if (g.speckleWindowSize > 0) {
             rc = launch_speckle(disp, dpe, dse, g.W, g.H, (g.minD - 1) * 16, g.speckleWindowSize,
                                 16 * g.speckleRange, h->speckle_ws, batch, st, &h->speckle_clean);

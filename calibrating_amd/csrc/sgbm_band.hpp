@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ d1,
     else both = (uint16_t)d1[ro + x0];
     // a band whose bounded wait expired computed on unpublished edge data: poison the whole result rather
     // than hand back plausible-looking garbage (camd_sgbm_status / the next compute report the error)
-    const bool poisoned = *err != 0;
+    const bool poisoned = (*err & 1u) != 0;  // bit 0 = a band pass timed out (bit 1, a refused pair, is per pair: k_poison_flagged)
     auto check = [&](int x, int v1) -> int {
         if (x >= g.minX1 && x < g.minX1 + g.W1 && v1 != INVALID_SCALED) {
             int _d = v1 >> 4, d_ = (v1 + 15) >> 4;

@@ -115,8 +115,8 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     constexpr int NP = DL / 2;            // packed cost registers per lane
     constexpr int SW2 = K / 2;
     constexpr int XS = 64 - (K - 1);      // output columns per strip
-    // every pixel cost is at most 2*ftzero + 63 per channel (ftzero <= 127) and P2 <= 24000 (normalise())
-    constexpr bool NOCARRY = K * K * CN * (2 * 127 + 63) + 24000 <= 65535;
+    // every pixel cost is at most 2*ftzero + 63 per channel; ftzero and P2 are bounded by the limits normalise() enforces
+    constexpr bool NOCARRY = K * K * CN * (2 * CAMD_MAX_FTZERO + 63) + CAMD_MAX_P2 <= 65535;
     extern __shared__ uint4 cs_lds[];  // everything in LDS is addressed in 16-byte quads: b128 reads and writes
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6, DW = NW * DL;

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmct_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BATCH=16
+BATCH=${BATCH:-16}
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/raw_$C -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --in-flight 1 --batch $BATCH --no-also --no-cpu-baseline "$@" > $OUT/log_$C.txt 2>&1
   find $OUT/raw_$C -name "*counter_collection*" -exec cp {} $OUT/$C.csv \;
@@ -32,6 +32,6 @@ doc = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- pyt
        "pairs_per_launch": $BATCH,
        "note": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE counts wide coalesced reads at half their size on gfx950 (MI355X_MICROARCH.md, HBM section); separate --pmc passes for the two counters",
        "kernels": res}
-json.dump(doc, open("$ROOT/gpurun_out/pmc_traffic_$TAG.json", "w"), indent=1)
+json.dump(doc, open("$ROOT/gpurun_out/pmc_traffic_$TAG.json", "w"), indent=1)  # (BATCH=64 bash tools/gpu_pmc_traffic.sh b64 -> the headline's pairs per launch)
 for k, v in res.items(): print("%-60s %.1f MB/pair" % (k[-60:], v["hbm_bytes_per_pair"] / 1e6))
 PY
