@@ -1391,9 +1391,22 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         auto launch_cost = [&](bool sat_kernel, uint32_t* ovf, int thresh) {
             int nchunks = 1;
             if (!sat_kernel) {
-                nchunks = div_up(8192, (long long)nstrips * ndblk * vbatch);
+                const long long per_chunk = (long long)nstrips * ndblk * vbatch;
+                nchunks = div_up(8192, per_chunk);
                 const int maxc = h->ga.H / 32 > 1 ? h->ga.H / 32 : 1;
                 nchunks = nchunks < 1 ? 1 : (nchunks > maxc ? maxc : nchunks);
+                // Few workgroups (one or two pairs per call): the launch is a handful of rounds over the chip's places
+                // (256 CUs x 3 eight-wave / 1 sixteen-wave workgroups), so the LAST round's fill decides: take the chunk
+                // count that minimises rounds x (rows walked per workgroup, incl. the K-1 rows every chunk recomputes).
+                // One 1080p RGB pair: 33 chunks = 1980 workgroups = 2.6 rounds of 37 rows -> 25 chunks = 1500 = 2 of 48.
+                const long long places = 256LL * (nw <= 8 ? 3 : 1);
+                if (per_chunk * nchunks < 6 * places) {
+                    long long best = -1;
+                    for (int nc = 1; nc <= maxc; nc++) {
+                        const long long cost = (long long)div_up(per_chunk * nc, places) * (div_up(h->ga.H, nc) + K - 1);
+                        if (best < 0 || cost < best) { best = cost; nchunks = nc; }
+                    }
+                }
             }
             const int rb = div_up(h->ga.H, nchunks);  // rows per chunk, in the longest range
             nchunks = div_up(h->ga.H, rb);
