@@ -1151,6 +1151,10 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     hipError_t e = hipSuccess;
     if (w1 > 0) {
         if (e == hipSuccess) e = hipMalloc((void**)&h->C, nvol * h->vol_elems * 2);
+        // the padded disparities d >= D of C hold P2 from here on: k_cost's all-padding waves do not write (sgbm_cost.hpp)
+        // (complete before the handle is handed out: the first compute may run on a stream the null stream does not order)
+        if (e == hipSuccess) e = hipMemsetD16(h->C, (unsigned short)g.P2, nvol * h->vol_elems);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipMalloc((void**)&h->S, nvol * h->vol_elems * 2);
         if (e == hipSuccess && way3) e = hipMalloc((void**)&h->rawv, nvol * align_up((size_t)vrows * width * 2, 256));
     }

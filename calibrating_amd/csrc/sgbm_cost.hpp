@@ -103,8 +103,13 @@ static inline size_t cost_lds_bytes(int cn, int nwaves)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #define KEEP_B128(q) asm volatile("" ::"v"(q))
 
+// The register ring of the vertical box sum holds K rows of 4 registers: from blockSize 9 on the kernel does not fit the
+// 80 registers of six waves per SIMD (blockSize 11 RGB, the reference's default: 40 spilled, 10.5 ms per 64 pairs of
+// 1000 x 562, D = 218); allowed 96 / 128 it runs without scratch traffic on fewer waves: 9.7 / 9.6 ms.
+constexpr int cost_min_waves(int K) { return K >= 11 ? 4 : (K >= 9 ? 5 : CAMD_COST_MIN_WAVES); }
+
 template <int CN, int K, bool SAT>
-__global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+__global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
                                                Geom g, int rb, int nchunks, size_t vol_stride, CostRanges cr,
                                                uint32_t* __restrict__ ovf, int ovf_thresh, uint32_t* __restrict__ neg)
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
     // The staged columns (NR of the right image, NL of the left) are cut into pieces of <= 60 columns; a piece sits
     // in consecutive lanes of ONE wave with two extra columns on each side (p needs the vertical sums of x-1, x+1;
     // the entry needs p of x-1, x+1).  Every lane finds its piece once; waves without a piece skip the staging.
-    int st_k = 0, st_lo = 0, st_hi = 0, st_img = -1;
+    int st_k = 0, st_lo = 0, st_hi = 0, st_img = -1, st_total = 0;  // st_total: threads that hold a staging lane
     {
         int v = 0;
         for (int sg = 0; sg < 2; sg++) {
@@ -174,7 +179,13 @@ __global__ __launch_bounds__(1024, CAMD_COST_MIN_WAVES) void k_cost(const uint8_
                 e += len;
             }
         }
+        st_total = v;
     }
+    // A wave whose DL disparities are all padding (d >= D: the tail of numDisparities rounded up to the volume's layout,
+    // 38 of 256 at the reference's D = 218) and that holds no staging lane has nothing to do and leaves before the first
+    // barrier (the hardware counts only live waves at s_barrier).  Nothing reads the padded part of C for its value --
+    // every consumer masks d >= D -- and camd_sgbm_create filled it with P2 once, which is what this wave would write.
+    if (db + w * DL >= g.D && w * 64 >= st_total) return;
     const bool stager = st_img >= 0;
     const bool st_store = stager && st_k >= st_lo && st_k < st_hi;
     const int st_col = (st_img == 1 ? lcol0 : rcol0) + st_k;
