@@ -341,15 +341,17 @@ size_t speckle_ws_bytes(int w, int h, int batch)
     return (size_t)batch * w * h * 2 * sizeof(int);  // parent + count per image: the whole batch in one launch
 }
 
-// `clean` (may be NULL): in -- the workspace already holds -1 in every parent entry (a previous call on the same
-// workspace completed); out -- true once all four kernels are queued.  When it is not known to be clean it is cleared
-// first (memset to 0xFF: parent = -1; count is zeroed where it is used).
+// `clean` (may be NULL): in -- the WHOLE workspace (`ws_bytes`: it may be sized for more images than this call's
+// `batch`) already holds -1 in every parent entry (it was cleared once and every call since completed); out -- true once
+// all kernels are queued.  When it is not known to be clean all of it is cleared first (memset to 0xFF: parent = -1;
+// count is zeroed where it is used).
 int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, int new_val, int max_size,
-                   int max_diff, void* ws, int batch, hipStream_t st, bool* clean)
+                   int max_diff, void* ws, size_t ws_bytes, int batch, hipStream_t st, bool* clean)
 {
     if (!ws) { set_error("speckle workspace is NULL"); return CAMD_ERR_BAD_ARG; }
+    if (ws_bytes < speckle_ws_bytes(w, h, batch)) { set_error("speckle workspace too small for %d images", batch); return CAMD_ERR_BAD_ARG; }
     int* parent = reinterpret_cast<int*>(ws);
-    if (!clean || !*clean) CAMD_HIP(hipMemsetAsync(ws, 0xFF, speckle_ws_bytes(w, h, batch), st));
+    if (!clean || !*clean) CAMD_HIP(hipMemsetAsync(ws, 0xFF, ws_bytes, st));
     if (clean) *clean = false;
     const int nseg = div_up(w, 64), nstrips = div_up(h, CC_ROWS), hblocks = div_up(w, 256);
     const int vwaves = (nseg - 1) * div_up(h, 64);
@@ -393,8 +395,8 @@ int camd_filter_speckles_s16(int16_t* img, int w, int h, int new_val, int max_sp
         set_error("camd_filter_speckles_s16: bad arguments");
         return CAMD_ERR_BAD_ARG;
     }
-    return launch_speckle(img, w, (size_t)w * h, w, h, new_val, max_speckle_size, max_diff, labels_ws, batch,
-                          (hipStream_t)stream, nullptr);  // a caller's scratch: nothing is known about its contents
+    return launch_speckle(img, w, (size_t)w * h, w, h, new_val, max_speckle_size, max_diff, labels_ws,
+                          speckle_ws_bytes(w, h, batch), batch, (hipStream_t)stream, nullptr);  // a caller's scratch: nothing is known about its contents
 }
 
 }  // extern "C"

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void k_gather_stripes(const int16_t* __restric
 int launch_median3(const int16_t* src, size_t src_pitch_e, size_t src_stride_e, int16_t* dst,
                    size_t dst_pitch_e, size_t dst_stride_e, int w, int h, int batch, hipStream_t st);
 int launch_speckle(int16_t* img, size_t pitch_e, size_t stride_e, int w, int h, int new_val, int max_size,
-                   int max_diff, void* ws, int batch, hipStream_t st, bool* clean);
+                   int max_diff, void* ws, size_t ws_bytes, int batch, hipStream_t st, bool* clean);
 size_t speckle_ws_bytes(int w, int h, int batch);
 
 // ------------------------------------------------------------------------------------------------
@@ -1651,7 +1651,8 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         MARK(ST_SPECKLE);
         if (g.speckleWindowSize > 0) {
             rc = launch_speckle(disp, dpe, dse, g.W, g.H, (g.minD - 1) * 16, g.speckleWindowSize,
-                                16 * g.speckleRange, h->speckle_ws, batch, st, &h->speckle_clean);
+                                16 * g.speckleRange, h->speckle_ws, speckle_ws_bytes(g.W, g.H, h->max_batch), batch, st,
+                                &h->speckle_clean);
             if (rc != CAMD_OK) return rc;
         }
     }

@@ -170,3 +170,31 @@ def test_c_abi_pitched_buffers(oracle):
             assert np.array_equal(got[:, :W], oracle.sgbm_compute(l, r, **p)), (path, i)
             assert (got[:, W:] == -999).all()                             # padding untouched
         _native.check(lib.camd_sgbm_destroy(hd))
+
+
+def test_c_abi_handle_sized_for_more_pairs_than_the_first_call(oracle):
+    """A handle created for max_batch pairs and first used with fewer (straight through the ABI: the Python wrapper sizes
+    its handle to the call): the speckle filter's union-find scratch is cleared once for the WHOLE handle, not for the
+    first call's pairs, so a later, larger call must find its part of it clean."""
+    import ctypes
+    from calibrating_amd import _native
+    H, W, D, nb = 70, 200, 32, 4
+    p = dict(minDisparity=0, numDisparities=D, blockSize=3, P1=24, P2=96, disp12MaxDiff=1, uniquenessRatio=5,
+             speckleWindowSize=60, speckleRange=1)
+    pairs = [synthetic.rectified_pair(seed=60 + i, H=H, W=W, D=D, cn=1) for i in range(nb)]
+    want = [oracle.sgbm_compute(l, r, **p) for l, r in pairs]
+    L = torch.from_numpy(np.stack([l for l, _ in pairs])).cuda()
+    R = torch.from_numpy(np.stack([r for _, r in pairs])).cuda()
+    lib, hd = _native.lib(), ctypes.c_void_p()
+    prm = _native.SgbmParams(**dict(dict(preFilterCap=0, mode=0), **p))
+    _native.check(lib.camd_sgbm_create(ctypes.byref(prm), W, H, 1, nb, ctypes.byref(hd)))
+    try:
+        for n in (1, nb, 2, nb):
+            out = torch.full((n, H, W), -999, dtype=torch.int16, device="cuda")
+            _native.check(lib.camd_sgbm_compute(hd, L.data_ptr(), R.data_ptr(), W, H * W, out.data_ptr(), W * 2, H * W * 2, n,
+                                                _native.current_stream()))
+            _native.check(lib.camd_sgbm_status(hd, _native.current_stream()))
+            for i in range(n):
+                assert np.array_equal(out[i].cpu().numpy(), want[i]), (n, i)
+    finally:
+        _native.check(lib.camd_sgbm_destroy(hd))
