@@ -120,7 +120,9 @@ int camd_sgbm_set_option(camd_sgbm* h, int option, int value);
  * invalid ((minDisparity - 1) * 16), and the next camd_sgbm_compute on the handle returns CAMD_ERR_HIP. */
 int camd_sgbm_status(camd_sgbm* h, void* stream);
 /* per-stage GPU time of the last compute, measured with hipEvents on `stream` (enable first).
- * stage names: camd_sgbm_stage_name(i), i in [0, camd_sgbm_num_stages()) */
+ * stage names: camd_sgbm_stage_name(i), i in [0, camd_sgbm_num_stages()): "cost", "hsum", "vsum" (the split cost pair),
+ * "scan" (aggregation; on the band path its first pass), "scan_last", "wta" (winner-take-all / LR check), "median",
+ * "speckle" */
 int camd_sgbm_set_profiling(camd_sgbm* h, int enable);
 int camd_sgbm_num_stages(void);
 const char* camd_sgbm_stage_name(int i);
