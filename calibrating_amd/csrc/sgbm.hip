@@ -966,7 +966,8 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     a.epoch = ++h->epoch;
     a.write_S = h->keep_S;
     CAMD_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
-    dim3 grid(h->nbands * batch), block(BAND_BLOCK);
+    // full passes: one workgroup per (pair, band); the row-parallel pass: the batch's rows in runs of R (sgbm_band.hpp)
+    dim3 grid(full ? h->nbands * batch : div_up((long long)batch * g.H, BAND_THREADS / g.lanes)), block(BAND_BLOCK);
     const bool pad = g.Dp != g.D;
 #define CAMD_BAND(LN, NVV, FF, MM, DG)                                                                 \
     do {                                                                                               \

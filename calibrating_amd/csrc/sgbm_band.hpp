@@ -262,7 +262,8 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
     // band-major order: band b of every pair is handed out before band b+1 of any pair, so with many
     // pairs in flight a workgroup's upstream band is usually far ahead by the time it starts (the
     // dependency (pair, b-1) always holds an earlier ticket)
-    const int band = ticket / a.npairs, pair = ticket % a.npairs;
+    // (the row-parallel pass has no bands: its groups take consecutive rows of the whole batch -- see below)
+    const int band = FULL ? ticket / a.npairs : 0;
     // roles: wave BAND_HELPER_WAVE is the helper, the others are compute waves numbered in wave order (ctid =
     // compute thread index).  Which wave helps decides which SIMD carries one compute wave less (see
     // tools/microtests/wave_simd_placement.hip)
@@ -272,8 +273,13 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
     const int ctid = helper ? (int)(threadIdx.x & 63) : (((wv > BAND_HELPER_WAVE ? wv - 1 : wv) << 6) | (int)(threadIdx.x & 63));
     const int grp = ctid / LANES, li = ctid % LANES;
     const int W1 = g.W1, H = g.H;
-    const int row = band * R + grp;  // row index in sweep order
-    const bool rvalid = !helper && row < H;
+    // FULL: row `grp` of band `band` of pair ticket % npairs.  !FULL: rows are independent, so the workgroups cut the
+    // rows of ALL pairs into runs of R without regard to pair boundaries (no partly filled last band per pair: 480 rows
+    // in bands of 56, 1080 in bands of 28); the groups past the last row of the batch idle on its last row
+    const long long grow = FULL ? 0 : min((long long)ticket * R + grp, (long long)a.npairs * H - 1);
+    const int pair = FULL ? ticket % a.npairs : (int)(grow / H);
+    const int row = FULL ? band * R + grp : (int)(grow % H);  // row index in sweep order
+    const bool rvalid = !helper && (FULL ? row < H : (long long)ticket * R + grp < (long long)a.npairs * H);
     const int y = a.sy > 0 ? row : H - 1 - row;
     const int glast = min(R, H - band * R) - 1;
     const bool has_prev = FULL && band > 0, has_next = FULL && band + 1 < a.nbands;
