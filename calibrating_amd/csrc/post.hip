@@ -21,45 +21,60 @@ __device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b)
 
 // A thread owns the pixel pair (2i, 2i+1) of a row: its own pair arrives as one dword (global loads take any byte
 // address on gfx950), the neighbour to the left and to the right as shorts, and the 19-exchange median network runs on
-// packed int16 pairs (v_pk_min_i16 / v_pk_max_i16): half the loads and half the exchanges per pixel.
+// packed int16 pairs (v_pk_min_i16 / v_pk_max_i16): half the loads and half the exchanges per pixel.  A block walks
+// POST_ROWS rows and keeps the three rows of the window in registers (one new row per output row; one row per block,
+// the round-3 form, was bound by the rate at which 250 K tiny workgroups start).
+constexpr int POST_ROWS = 8;
+
 __global__ __launch_bounds__(256) void k_median3(const int16_t* __restrict__ src, size_t sp, size_t ss,
                                                  int16_t* __restrict__ dst, size_t dp, size_t ds, int w, int h)
 {
     const int x = 2 * (blockIdx.x * 256 + threadIdx.x);
-    const int y = blockIdx.y;
+    const int y0 = blockIdx.y * POST_ROWS, y1 = min(y0 + POST_ROWS, h);
     if (x >= w) return;
     const bool two = x + 1 < w;  // (the last pair of an odd-width row holds one pixel)
     const int16_t* s = src + (size_t)blockIdx.z * ss;
     const int xl = x > 0 ? x - 1 : 0, xr = min(x + 2, w - 1);
-    const int16_t* rows[3] = {s + (size_t)(y > 0 ? y - 1 : y) * sp, s + (size_t)y * sp,
-                              s + (size_t)(y < h - 1 ? y + 1 : y) * sp};
-    uint32_t p[9];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
+    uint32_t win[3][3];  // [row of the window][left neighbours | own pair | right neighbours]
+    auto load_row = [&](int y, uint32_t (&r)[3]) {
+        const int16_t* row = s + (size_t)min(max(y, 0), h - 1) * sp;  // replicate border
         uint32_t own;
-        if (two) __builtin_memcpy(&own, rows[r] + x, 4);
-        else own = dup16((uint16_t)rows[r][x]);  // replicate border: the missing right neighbour is the pixel itself
-        const uint32_t l = (uint16_t)rows[r][xl], rr = (uint16_t)rows[r][xr];
-        p[3 * r + 0] = l | (own << 16);           // left neighbours of (x, x+1):   (x-1, x)
-        p[3 * r + 1] = own;                       //                                 (x,   x+1)
-        p[3 * r + 2] = (own >> 16) | (rr << 16);  // right neighbours:              (x+1, x+2)
+        if (two) __builtin_memcpy(&own, row + x, 4);
+        else own = dup16((uint16_t)row[x]);  // replicate border: the missing right neighbour is the pixel itself
+        const uint32_t l = (uint16_t)row[xl], rr = (uint16_t)row[xr];
+        r[0] = l | (own << 16);           // left neighbours of (x, x+1):   (x-1, x)
+        r[1] = own;                       //                                 (x,   x+1)
+        r[2] = (own >> 16) | (rr << 16);  // right neighbours:              (x+1, x+2)
+    };
+    load_row(y0 - 1, win[0]);
+    load_row(y0, win[1]);
+#pragma unroll
+    for (int k = 0; k < POST_ROWS; k++) {
+        const int y = y0 + k;
+        if (y >= y1) break;
+        load_row(y + 1, win[(k + 2) % 3]);
+        uint32_t p[9];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) p[3 * r + c] = win[(k + r) % 3][c];
+        // median of 9 by the classic 19-exchange network
+        sort2(p[1], p[2]); sort2(p[4], p[5]); sort2(p[7], p[8]); sort2(p[0], p[1]);
+        sort2(p[3], p[4]); sort2(p[6], p[7]); sort2(p[1], p[2]); sort2(p[4], p[5]);
+        sort2(p[7], p[8]); sort2(p[0], p[3]); sort2(p[5], p[8]); sort2(p[4], p[7]);
+        sort2(p[3], p[6]); sort2(p[1], p[4]); sort2(p[2], p[5]); sort2(p[4], p[7]);
+        sort2(p[4], p[2]); sort2(p[6], p[4]); sort2(p[4], p[2]);
+        int16_t* o = dst + (size_t)blockIdx.z * ds + (size_t)y * dp + x;
+        if (two) __builtin_memcpy(o, &p[4], 4);
+        else *o = (int16_t)(p[4] & 0xffffu);
     }
-    // median of 9 by the classic 19-exchange network
-    sort2(p[1], p[2]); sort2(p[4], p[5]); sort2(p[7], p[8]); sort2(p[0], p[1]);
-    sort2(p[3], p[4]); sort2(p[6], p[7]); sort2(p[1], p[2]); sort2(p[4], p[5]);
-    sort2(p[7], p[8]); sort2(p[0], p[3]); sort2(p[5], p[8]); sort2(p[4], p[7]);
-    sort2(p[3], p[6]); sort2(p[1], p[4]); sort2(p[2], p[5]); sort2(p[4], p[7]);
-    sort2(p[4], p[2]); sort2(p[6], p[4]); sort2(p[4], p[2]);
-    int16_t* o = dst + (size_t)blockIdx.z * ds + (size_t)y * dp + x;
-    if (two) __builtin_memcpy(o, &p[4], 4);
-    else *o = (int16_t)(p[4] & 0xffffu);
 }
 
 int launch_median3(const int16_t* src, size_t sp, size_t ss, int16_t* dst, size_t dp, size_t ds, int w, int h,
                    int batch, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_median3, dim3(div_up(div_up(w, 2), 256), h, batch), dim3(256), 0, st, src, sp, ss, dst, dp, ds,
-                       w, h);
+    hipLaunchKernelGGL(k_median3, dim3(div_up(div_up(w, 2), 256), div_up(h, POST_ROWS), batch), dim3(256), 0, st, src, sp,
+                       ss, dst, dp, ds, w, h);
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
 }

@@ -1610,7 +1610,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
 
     MARK(ST_WTA);
     if (band && !way3) {
-        hipLaunchKernelGGL(k_lrcheck, dim3(div_up(div_up(g.W, 2), 256), g.H, batch), dim3(256), 0, st, h->d1, h->keys, h->raw,
+        hipLaunchKernelGGL(k_lrcheck, dim3(div_up(div_up(g.W, 2), 256), div_up(g.H, LRCHECK_ROWS), batch), dim3(256), 0, st, h->d1, h->keys, h->raw,
                            (size_t)g.W, raw_stride, g, h->err);
         CAMD_LAUNCH_CHECK();
         CAMD_HIP(hipMemcpyAsync(h->err_host, h->err, 4, hipMemcpyDeviceToHost, st));
@@ -1618,7 +1618,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         // winner-take-all + LR check per stripe row, then every image row is taken from the stripe that owns it
         const size_t rawv_stride = align_up((size_t)h->ga.H * g.W * 2, 256) / 2;
         if (band && way3_inline) {
-            hipLaunchKernelGGL(k_lrcheck, dim3(div_up(div_up(g.W, 2), 256), h->ga.H, vbatch), dim3(256), 0, st, h->d1, h->keys,
+            hipLaunchKernelGGL(k_lrcheck, dim3(div_up(div_up(g.W, 2), 256), div_up(h->ga.H, LRCHECK_ROWS), vbatch), dim3(256), 0, st, h->d1, h->keys,
                                h->rawv, (size_t)g.W, rawv_stride, h->ga, h->err);
             CAMD_LAUNCH_CHECK();
         } else {

@@ -581,6 +581,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a
 
 // left-right check of one row from the candidates / right-view keys the FINAL band pass produced; a thread owns the
 // pixel pair (2i, 2i+1): candidates in and disparities out travel as one dword per pair
+constexpr int LRCHECK_ROWS = 8;  // rows a block walks (one row per block was bound by the rate at which workgroups start)
 __global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ d1, const uint32_t* __restrict__ keys,
                                                  int16_t* __restrict__ out, size_t out_pitch_e, size_t out_stride_e,
                                                  Geom g, const uint32_t* __restrict__ err)
@@ -588,44 +589,53 @@ __global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ d1,
     const int x0 = 2 * (blockIdx.x * 256 + threadIdx.x);
     if (x0 >= g.W) return;
     const bool two = x0 + 1 < g.W;
-    const int y = blockIdx.y, pair = blockIdx.z;
-    const size_t ro = ((size_t)pair * g.H + y) * (size_t)g.W;
+    const int ya = blockIdx.y * LRCHECK_ROWS, yb = min(ya + LRCHECK_ROWS, g.H), pair = blockIdx.z;
     const int INVALID_SCALED = (g.minD - 1) * 16;
-    uint32_t both;
-    if (two) __builtin_memcpy(&both, d1 + ro + x0, 4);
-    else both = (uint16_t)d1[ro + x0];
     // a band whose bounded wait expired computed on unpublished edge data: poison the whole result rather
     // than hand back plausible-looking garbage (camd_sgbm_status / the next compute report the error)
     const bool poisoned = (*err & 1u) != 0;  // bit 0 = a band pass timed out (bit 1, a refused pair, is per pair: k_poison_flagged)
-    auto check = [&](int x, int v1) -> int {
-        if (x >= g.minX1 && x < g.minX1 + g.W1 && v1 != INVALID_SCALED) {
-            int _d = v1 >> 4, d_ = (v1 + 15) >> 4;
-            int _x = x - _d, x_ = x - d_;
-            bool bad = false;
-            if (0 <= _x && _x < g.W) {
-                uint32_t k = keys[ro + _x];
-                int v = k == KEY_INIT ? INVALID_SCALED : (int)(0xffffu - (k & 0xffffu)) + g.minD;
-                bad = v >= g.minD && abs(v - _d) > g.d12;
-            }
-            if (bad) {
-                bad = false;
-                if (0 <= x_ && x_ < g.W) {
-                    uint32_t k = keys[ro + x_];
-                    int v = k == KEY_INIT ? INVALID_SCALED : (int)(0xffffu - (k & 0xffffu)) + g.minD;
-                    bad = v >= g.minD && abs(v - d_) > g.d12;
+    uint32_t both[LRCHECK_ROWS];
+#pragma unroll
+    for (int k = 0; k < LRCHECK_ROWS; k++) {  // all candidate rows requested before the first dependent gather
+        const size_t ro = ((size_t)pair * g.H + min(ya + k, g.H - 1)) * (size_t)g.W;
+        if (two) __builtin_memcpy(&both[k], d1 + ro + x0, 4);
+        else both[k] = (uint16_t)d1[ro + x0];
+    }
+#pragma unroll
+    for (int k = 0; k < LRCHECK_ROWS; k++) {
+        const int y = ya + k;
+        if (y >= yb) break;
+        const size_t ro = ((size_t)pair * g.H + y) * (size_t)g.W;
+        auto check = [&](int x, int v1) -> int {
+            if (x >= g.minX1 && x < g.minX1 + g.W1 && v1 != INVALID_SCALED) {
+                int _d = v1 >> 4, d_ = (v1 + 15) >> 4;
+                int _x = x - _d, x_ = x - d_;
+                bool bad = false;
+                if (0 <= _x && _x < g.W) {
+                    uint32_t kk = keys[ro + _x];
+                    int v = kk == KEY_INIT ? INVALID_SCALED : (int)(0xffffu - (kk & 0xffffu)) + g.minD;
+                    bad = v >= g.minD && abs(v - _d) > g.d12;
                 }
+                if (bad) {
+                    bad = false;
+                    if (0 <= x_ && x_ < g.W) {
+                        uint32_t kk = keys[ro + x_];
+                        int v = kk == KEY_INIT ? INVALID_SCALED : (int)(0xffffu - (kk & 0xffffu)) + g.minD;
+                        bad = v >= g.minD && abs(v - d_) > g.d12;
+                    }
+                }
+                if (bad) v1 = INVALID_SCALED;
             }
-            if (bad) v1 = INVALID_SCALED;
-        }
-        return poisoned ? INVALID_SCALED : v1;
-    };
-    const uint32_t lo = (uint32_t)check(x0, (int)(int16_t)(both & 0xffffu)) & 0xffffu;
-    int16_t* o = out + (size_t)pair * out_stride_e + (size_t)y * out_pitch_e + x0;
-    if (two) {
-        const uint32_t r = lo | ((uint32_t)check(x0 + 1, (int)(int16_t)(both >> 16)) << 16);
-        __builtin_memcpy(o, &r, 4);
-    } else
-        *o = (int16_t)lo;
+            return poisoned ? INVALID_SCALED : v1;
+        };
+        const uint32_t lo = (uint32_t)check(x0, (int)(int16_t)(both[k] & 0xffffu)) & 0xffffu;
+        int16_t* o = out + (size_t)pair * out_stride_e + (size_t)y * out_pitch_e + x0;
+        if (two) {
+            const uint32_t r = lo | ((uint32_t)check(x0 + 1, (int)(int16_t)(both[k] >> 16)) << 16);
+            __builtin_memcpy(o, &r, 4);
+        } else
+            *o = (int16_t)lo;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_wta_init(uint32_t* keys, int16_t* d1, size_t n, int invalid)
