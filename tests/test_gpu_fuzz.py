@@ -65,3 +65,25 @@ def test_speckle_workspace_of_a_handle_survives_many_pairs(oracle):
         got = m.compute(np.stack([pairs[i][0] for i in order]), np.stack([pairs[i][1] for i in order]))
         for k, i in enumerate(order):
             assert np.array_equal(got[k], want[i]), (order, k)
+
+
+@pytest.mark.parametrize("h,w,nb", [(1080, 1920, 3), (2160, 3840, 1), (1081, 1923, 2)])
+def test_speckle_full_size(oracle, h, w, nb):
+    """The speckle filter at BASELINE's image sizes (and an odd one): piecewise-smooth disparity-like images with noise
+    speckles, holes and one long thin structure, against cv2.filterSpeckles' flood fill restated in the oracle."""
+    import numpy as np
+    from calibrating_amd import imgproc
+    rng = np.random.default_rng(h + w)
+    imgs = []
+    for i in range(nb):
+        img = fuzzers.speckle_image(rng, 0, h, w, -16)
+        img[h // 3, :] = 7000          # a one-pixel line across every segment
+        img[:, w // 2] = 7000          # ... and down every strip
+        img[h // 3 + 2:h // 3 + 40:2, ::3] = 9000  # a comb of isolated pixels (size-1 components)
+        imgs.append(img)
+    imgs = np.stack(imgs)
+    got = imgproc.filterSpeckles(imgs, -16, 200, 32)
+    for i in range(nb):
+        want = oracle.filter_speckles_s16(imgs[i], -16, 200, 32)
+        assert (want != imgs[i]).any()
+        assert np.array_equal(got[i], want), (i, int((got[i] != want).sum()))
