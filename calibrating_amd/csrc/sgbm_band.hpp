@@ -42,6 +42,9 @@ namespace camd {
 #ifndef CAMD_BAND_HELPER_WAVE
 #define CAMD_BAND_HELPER_WAVE CAMD_BAND_COMPUTE_WAVES    // which wave of the workgroup is the helper (default: the last)
 #endif
+#ifndef CAMD_BAND_MIN_WAVES
+#define CAMD_BAND_MIN_WAVES 4                            // occupancy target (waves per SIMD) of the D <= 128 instantiations
+#endif
 static constexpr int BAND_THREADS = 64 * CAMD_BAND_COMPUTE_WAVES;  // compute threads
 static constexpr int BAND_BLOCK = BAND_THREADS + 64;     // + one helper wave
 static constexpr int BAND_HELPER_WAVE = CAMD_BAND_HELPER_WAVE;
@@ -235,7 +238,7 @@ __device__ __forceinline__ void band_wta_flush(const BandArgs& a, const Geom& g,
 // MODE: 0 = first pass (S written), 2 = final (S read, WTA; S stored only for the parity hook)
 // DIAG = false (MODE_HH4): the two diagonal directions are left out (their slots travel as zeros)
 template <int LANES, int NV, bool FULL, int MODE, bool PAD, bool DIAG = true, bool TIE8 = false>
-__global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? 4 : 2) void k_band(BandArgs a, Geom g)
+__global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void k_band(BandArgs a, Geom g)
 {
     constexpr int NR = 4 * NV;
     constexpr int R = BAND_THREADS / LANES;
