@@ -365,8 +365,10 @@ __global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t*
                         ovf_max = pk_max_u16(pk_max_u16(ovf_max, pk_max_u16(acc[0], acc[1])), pk_max_u16(acc[2], acc[3]));
                 }
                 // entries of row r+1 from the rows fetched one step ago; then fetch for row r+2
+#ifndef CAMD_COST_DBG_NOSTAGE  // (measurement only: what the staging costs; the results are wrong without it)
                 stage_entries((r + 1) & 1);
                 fetch_rows(row_of(r + 2));
+#endif
                 __syncthreads();
             }
         }
