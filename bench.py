@@ -445,15 +445,24 @@ def config_c5(ca, synthetic, dev, streams, nb=256):
     W, H, D = 640, 480, 64
     P = dict(minDisparity=0, numDisparities=D, blockSize=5, P1=8 * 3 * 25, P2=32 * 3 * 25, disp12MaxDiff=1, preFilterCap=0,
              uniquenessRatio=10, speckleWindowSize=100, speckleRange=2, mode=0)
-    pairs = [synthetic.scene_pair(100 + i, W, H, 3) for i in range(8)]
+    # Input: a REAL stereo scene -- four textured planes ray-cast through the rig's Brown models (synthetic.render_plane_pair),
+    # so that the matcher finds the smooth disparities the LR check and the speckle filter are made for.  Rounds 1-3
+    # fed unrelated random textures (synthetic.scene_pair): every SGBM kernel costs the same there, but the matcher's
+    # output is all speckles, the worst case of the (data-dependent) speckle filter; that input is still reported below.
+    rec = synthetic.rig(W, H)
+    planes = [((0.3, 0.1, 1.0), 2.0), ((-0.2, 0.15, 1.0), 1.6), ((0.0, 0.0, 1.0), 2.5), ((0.1, -0.25, 1.0), 1.3)]
+    pairs = [synthetic.render_plane_pair(rec, n_, d_, seed=i)[:2] for i, (n_, d_) in enumerate(planes)]
+    noise = [synthetic.scene_pair(100 + i, W, H, 3) for i in range(8)]
 
-    def batch(n):
-        return (torch.from_numpy(np.stack([pairs[i % 8][0] for i in range(n)])).to(dev),
-                torch.from_numpy(np.stack([pairs[i % 8][1] for i in range(n)])).to(dev))
+    def batch(n, src=None):
+        src = pairs if src is None else src
+        return (torch.from_numpy(np.stack([src[i % len(src)][0] for i in range(n)])).to(dev),
+                torch.from_numpy(np.stack([src[i % len(src)][1] for i in range(n)])).to(dev))
     B1, B2 = batch(nb)
     r = depth_path_rate(ca, synthetic, P, B1, B2, streams, W, H, D, 3, max_depth=3.5, reps=6)
-    r["workload"] = ("640x480 RGB pairs through the whole get_depth path (rectify x2, SGBM numDisparities=64 blockSize=5 "
-                     "LR check on speckle 100/2, disp_to_depth, unrectify, undistort), %d pairs per call" % nb)
+    r["workload"] = ("640x480 RGB pairs (rendered textured planes: a real stereo scene) through the whole get_depth path "
+                     "(rectify x2, SGBM numDisparities=64 blockSize=5 LR check on speckle 100/2, disp_to_depth, unrectify, "
+                     "undistort), %d pairs per call" % nb)
     st = ca.Stereo.load(synthetic.rig(W, H))
     st.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(P, max_size=max(W, H))), max_depth=3.5)
     r["per_stage"] = depth_path_stages(st, B1, B2, W, H, D, 3)
@@ -463,6 +472,13 @@ def config_c5(ca, synthetic, dev, streams, nb=256):
     b1, b2 = batch(128)
     r128 = depth_path_rate(ca, synthetic, P, b1, b2, streams, W, H, D, 3, max_depth=3.5, reps=6)
     r["at_128_pairs_per_call"] = {k: r128[k] for k in ("pairs_per_s", "single_stream_pairs_per_s", "frac")}
+    del b1, b2
+    # the input of rounds 1-3 (unrelated random textures: the speckle filter's worst case), same pairs per call
+    n1, n2 = batch(nb, noise)
+    rn = depth_path_rate(ca, synthetic, P, n1, n2, streams, W, H, D, 3, max_depth=3.5, reps=6)
+    r["random_texture_input"] = dict({k: rn[k] for k in ("pairs_per_s", "single_stream_pairs_per_s", "frac")},
+                                     note="left / right images unrelated: the matcher's output is all speckles; only the "
+                                          "speckle filter's time depends on the content")
     return r
 
 
