@@ -10,7 +10,13 @@ stereo = ca.Stereo.load(synthetic.rig(W, H))
 cfg = dict(max_size=max(W, H), minDisparity=0, numDisparities=D, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1, uniquenessRatio=10,
            speckleWindowSize=100, speckleRange=2)
 stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=3.5)
-pairs = [synthetic.scene_pair(100 + i, W, H, 3) for i in range(4)]
+# input: unrelated random textures (the speckle filter's worst case; default, as in rounds 1-3) or, with a fifth
+# argument "scene", rendered textured planes (a real stereo scene: smooth disparities)
+if len(sys.argv) > 5 and sys.argv[5] == "scene":
+    planes = [((0.3, 0.1, 1.0), 2.0), ((-0.2, 0.15, 1.0), 1.6), ((0.0, 0.0, 1.0), 2.5), ((0.1, -0.25, 1.0), 1.3)]
+    pairs = [synthetic.render_plane_pair(synthetic.rig(W, H), n_, d_, seed=i)[:2] for i, (n_, d_) in enumerate(planes)]
+else:
+    pairs = [synthetic.scene_pair(100 + i, W, H, 3) for i in range(4)]
 B1 = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(nb)])).to(dev)
 B2 = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(nb)])).to(dev)
 for _ in range(2): stereo.get_depth_batch(B1, B2)
