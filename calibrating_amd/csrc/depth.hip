@@ -78,11 +78,10 @@ __global__ __launch_bounds__(256) void k_unrectify(const double* __restrict__ de
         double r = 0.;
         if (inside) {
             const double zz = *p;
-            // M[2,0]*(x*z) + M[2,1]*(y*z) + M[2,2]*z, products and sums individually rounded
-            double a = __dmul_rn(m0, __dmul_rn(fx, zz));
-            double b = __dmul_rn(m1, __dmul_rn(fy, zz));
-            double c = __dmul_rn(m2, zz);
-            r = __dadd_rn(__dadd_rn(a, b), c);
+            // row 2 of M @ [x*z, y*z, z] as NumPy's matmul (a BLAS dgemm with FMA kernels) rounds it:
+            // fma(M22, z, fma(M21, y*z, M20*(x*z))) -- bit-identical with the reference's own run
+            // (tests/golden/reference_plumbing.npz); individually rounded products and sums are 1 ulp off in 1 of 4 pixels
+            r = __fma_rn(m2, zz, __fma_rn(m1, __dmul_rn(fy, zz), __dmul_rn(m0, __dmul_rn(fx, zz))));
         }
         *o = r;
     }

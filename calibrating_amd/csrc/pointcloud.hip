@@ -28,6 +28,19 @@ __device__ __forceinline__ double pc_sample(const double* __restrict__ depth, co
 }
 
 // order-preserving map double -> u64 (total order of the reals; -0.0 < +0.0)
+// Matrix products the way NumPy's matmul rounds them: the reference's (K^-1 @ P.T).T, (T @ P4.T).T and P @ K.T are BLAS
+// dgemm calls whose x86-64 kernels accumulate the k terms in order with fused multiply-adds, starting from the plain
+// first product.  Measured against the reference's own run (tests/golden/reference_plumbing.npz) and against NumPy on
+// every shape involved: this chain reproduces the bits, individually rounded products and sums differ in 1 of 4 values.
+__device__ __forceinline__ double dot3(double a0, double a1, double a2, double b0, double b1, double b2)
+{
+    return __fma_rn(a2, b2, __fma_rn(a1, b1, __dmul_rn(a0, b0)));
+}
+__device__ __forceinline__ double dot4(double a0, double a1, double a2, double a3, double b0, double b1, double b2, double b3)
+{
+    return __fma_rn(a3, b3, __fma_rn(a2, b2, __fma_rn(a1, b1, __dmul_rn(a0, b0))));
+}
+
 __device__ __forceinline__ unsigned long long zkey(double z)
 {
     unsigned long long b = (unsigned long long)__double_as_longlong(z);
@@ -106,9 +119,9 @@ __global__ __launch_bounds__(256) void k_pc_emit(const double* __restrict__ dept
             const double u = g.rate == 1.0 ? (double)x : (double)x / g.rate;
             const double v = g.rate == 1.0 ? (double)y : (double)y / g.rate;
             const double p0 = u * z, p1 = v * z, p2 = 1.0 * z;
-            points[pos * 3 + 0] = Ki0 * p0 + Ki1 * p1 + Ki2 * p2;
-            points[pos * 3 + 1] = Ki3 * p0 + Ki4 * p1 + Ki5 * p2;
-            points[pos * 3 + 2] = Ki6 * p0 + Ki7 * p1 + Ki8 * p2;
+            points[pos * 3 + 0] = dot3(Ki0, Ki1, Ki2, p0, p1, p2);
+            points[pos * 3 + 1] = dot3(Ki3, Ki4, Ki5, p0, p1, p2);
+            points[pos * 3 + 2] = dot3(Ki6, Ki7, Ki8, p0, p1, p2);
             if (uv) { uv[pos * 2] = u; uv[pos * 2 + 1] = v; }
         }
         __syncthreads();
@@ -130,9 +143,9 @@ struct Mat33 { double m[9]; };
 __device__ __forceinline__ void zbuffer_point(double X, double Y, double Z, const Mat33& K, int w, int h,
                                               unsigned long long* __restrict__ keys)
 {
-    const double xs = X * K.m[0] + Y * K.m[1] + Z * K.m[2];
-    const double ys = X * K.m[3] + Y * K.m[4] + Z * K.m[5];
-    const double zs = X * K.m[6] + Y * K.m[7] + Z * K.m[8];
+    const double xs = dot3(X, Y, Z, K.m[0], K.m[1], K.m[2]);
+    const double ys = dot3(X, Y, Z, K.m[3], K.m[4], K.m[5]);
+    const double zs = dot3(X, Y, Z, K.m[6], K.m[7], K.m[8]);
     const double u = xs / zs, v = ys / zs;
     const double ru = rint(u), rv = rint(v);  // np.round: half to even
     if (!(ru >= 0.0 && ru < (double)w && rv >= 0.0 && rv < (double)h)) return;  // also drops NaN / inf
@@ -159,9 +172,9 @@ __global__ __launch_bounds__(256) void k_apply_T(const double* __restrict__ src,
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double x = src[i * 3], y = src[i * 3 + 1], z = src[i * 3 + 2];
-    dst[i * 3 + 0] = T.m[0] * x + T.m[1] * y + T.m[2] * z + T.m[3] * 1.0;
-    dst[i * 3 + 1] = T.m[4] * x + T.m[5] * y + T.m[6] * z + T.m[7] * 1.0;
-    dst[i * 3 + 2] = T.m[8] * x + T.m[9] * y + T.m[10] * z + T.m[11] * 1.0;
+    dst[i * 3 + 0] = dot4(T.m[0], T.m[1], T.m[2], T.m[3], x, y, z, 1.0);
+    dst[i * 3 + 1] = dot4(T.m[4], T.m[5], T.m[6], T.m[7], x, y, z, 1.0);
+    dst[i * 3 + 2] = dot4(T.m[8], T.m[9], T.m[10], T.m[11], x, y, z, 1.0);
 }
 
 // Cam.project_cam2_depth fused: depth2 grid cell -> point (K2^-1) -> T -> K1 projection -> z-buffer
@@ -175,12 +188,12 @@ __global__ __launch_bounds__(256) void k_project_depth(const double* __restrict_
     const double u = g.rate == 1.0 ? (double)x : (double)x / g.rate;
     const double v = g.rate == 1.0 ? (double)y : (double)y / g.rate;
     const double p0 = u * z, p1 = v * z, p2 = 1.0 * z;
-    const double X = K2inv.m[0] * p0 + K2inv.m[1] * p1 + K2inv.m[2] * p2;
-    const double Y = K2inv.m[3] * p0 + K2inv.m[4] * p1 + K2inv.m[5] * p2;
-    const double Z = K2inv.m[6] * p0 + K2inv.m[7] * p1 + K2inv.m[8] * p2;
-    const double X1 = T.m[0] * X + T.m[1] * Y + T.m[2] * Z + T.m[3] * 1.0;
-    const double Y1 = T.m[4] * X + T.m[5] * Y + T.m[6] * Z + T.m[7] * 1.0;
-    const double Z1 = T.m[8] * X + T.m[9] * Y + T.m[10] * Z + T.m[11] * 1.0;
+    const double X = dot3(K2inv.m[0], K2inv.m[1], K2inv.m[2], p0, p1, p2);
+    const double Y = dot3(K2inv.m[3], K2inv.m[4], K2inv.m[5], p0, p1, p2);
+    const double Z = dot3(K2inv.m[6], K2inv.m[7], K2inv.m[8], p0, p1, p2);
+    const double X1 = dot4(T.m[0], T.m[1], T.m[2], T.m[3], X, Y, Z, 1.0);
+    const double Y1 = dot4(T.m[4], T.m[5], T.m[6], T.m[7], X, Y, Z, 1.0);
+    const double Z1 = dot4(T.m[8], T.m[9], T.m[10], T.m[11], X, Y, Z, 1.0);
     zbuffer_point(X1, Y1, Z1, K1, w1, h1, keys);
 }
 

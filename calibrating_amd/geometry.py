@@ -24,10 +24,10 @@ def rodrigues(r):
     r = np.asarray(r, np.float64)
     if r.size == 3:
         r = r.reshape(3)
-        theta = np.linalg.norm(r)
+        theta = float(np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]))
         if theta < np.finfo(np.float64).eps:
             return np.eye(3)
-        k = r / theta
+        k = r * (1.0 / theta)  # OpenCV multiplies by the reciprocal (cvRodrigues2: itheta = 1 / theta; r *= itheta)
         c, s = np.cos(theta), np.sin(theta)
         kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
         return c * np.eye(3) + (1 - c) * np.outer(k, k) + s * kx
@@ -61,7 +61,7 @@ def rotate_shortest_of_two_vecs(v1, v2, return_rodrigues=False):
     a, b = np.asarray(v1, np.float64), np.asarray(v2, np.float64)
     axis = np.cross(a, b)
     angle = np.arccos(np.sum(a * b) / np.linalg.norm(a) / np.linalg.norm(b))
-    rvec = axis * (angle / (np.linalg.norm(axis) + eps))
+    rvec = angle * axis / (np.linalg.norm(axis) + eps)  # this order of operations: the reference's rounding
     return rvec if return_rodrigues else rodrigues(rvec)
 
 

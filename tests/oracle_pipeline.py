@@ -53,10 +53,18 @@ def matcher_disparity(oracle, cfg, r1, r2):
     return sd * w / hw[1]
 
 
-def oracle_get_depth(oracle, stereo, cfg, img1, img2):
-    """Every entry of get_depth's result dict for the SGBM plugin built from ``cfg`` (incl. ``max_size``)."""
+def oracle_get_depth(oracle, stereo, cfg, img1, img2, plugin=None, return_unrectify_depth=True):
+    """Every entry of get_depth's result dict for the SGBM plugin built from ``cfg`` (incl. ``max_size``), or for a
+    foreign ``plugin`` (a callable on the rectified ndarrays returning a disparity array or a dict, :506-509)."""
     r1, r2, mask = rectified_pair(oracle, stereo, img1, img2)
-    disparity = matcher_disparity(oracle, cfg, r1, r2)
+    extra = {}
+    if plugin is None:
+        disparity = matcher_disparity(oracle, cfg, r1, r2)
+    else:
+        disparity = plugin(r1, r2)
+        if isinstance(disparity, dict):
+            extra = {k: v for k, v in disparity.items() if k != "disparity"}
+            disparity = disparity["disparity"]
     if stereo.translation_rectify_img:
         disparity += stereo.min_disparity
     disparity = mask * disparity
@@ -64,12 +72,13 @@ def oracle_get_depth(oracle, stereo, cfg, img1, img2):
         depth = 1.0 * stereo.baseline * stereo.K[0, 0] / disparity  # float64 scalar / float32 array -> float64
     depth[depth > stereo.get_max_depth()] = 0
     depth[depth < 0] = 0
-    maps = oracle.init_undistort_rectify_map(stereo.K, None, stereo.R1.T, stereo.cam1.K, stereo.cam1.xy)
-    M = stereo.R1.T @ np.linalg.inv(stereo.K)
-    unrect = oracle.unrectify_depth(depth, M[2], *maps)
-    undist = oracle.undistort_u8(img1, stereo.cam1.K, stereo.cam1.D)
-    return dict(rectify_img1=r1, rectify_img2=r2, disparity=disparity, rectify_depth=depth,
-                unrectify_depth=unrect, undistort_img1=undist)
+    result = dict(extra, rectify_img1=r1, rectify_img2=r2, disparity=disparity, rectify_depth=depth)
+    if return_unrectify_depth:
+        maps = oracle.init_undistort_rectify_map(stereo.K, None, stereo.R1.T, stereo.cam1.K, stereo.cam1.xy)
+        M = stereo.R1.T @ np.linalg.inv(stereo.K)
+        result.update(unrectify_depth=oracle.unrectify_depth(depth, M[2], *maps),
+                      undistort_img1=oracle.undistort_u8(img1, stereo.cam1.K, stereo.cam1.D))
+    return result
 
 
 def compare(got, ref, depth_tol=1e-4, keys=None):
