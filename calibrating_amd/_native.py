@@ -43,6 +43,8 @@ SIGNATURES = {
     "camd_last_error": (ctypes.c_char_p, []),
     "camd_version": (c_int, []),
     "camd_device_ok": (c_int, []),
+    "camd_stream_create_cu_mask": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p)]),
+    "camd_stream_destroy": (c_int, [c_void_p]),
     "camd_sgbm_workspace_bytes": (c_size_t, [ctypes.POINTER(SgbmParams), c_int, c_int, c_int, c_int]),
     "camd_sgbm_create": (c_int, [ctypes.POINTER(SgbmParams), c_int, c_int, c_int, c_int,
                                  ctypes.POINTER(c_void_p)]),

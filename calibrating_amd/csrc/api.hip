@@ -48,4 +48,32 @@ int camd_device_ok(void)
     return CAMD_OK;
 }
 
+int camd_stream_create_cu_mask(const uint32_t* cu_mask, int nwords, void** stream)
+{
+    if (!cu_mask || nwords <= 0 || !stream) { camd::set_error("camd_stream_create_cu_mask: bad arguments"); return CAMD_ERR_BAD_ARG; }
+    int rc = camd_device_ok();
+    if (rc != CAMD_OK) return rc;
+    hipStream_t st = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, cu_mask);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        camd::set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+        return CAMD_ERR_HIP;
+    }
+    *stream = (void*)st;
+    return CAMD_OK;
+}
+
+int camd_stream_destroy(void* stream)
+{
+    if (!stream) return CAMD_OK;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        camd::set_error("hipStreamDestroy: %s", hipGetErrorString(e));
+        return CAMD_ERR_HIP;
+    }
+    return CAMD_OK;
+}
+
 }  // extern "C"

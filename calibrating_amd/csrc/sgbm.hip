@@ -745,6 +745,7 @@ struct camd_sgbm {
     int keep_S;           // band path: also store S in the final pass (stage-wise parity hook)
     int cost_path;        // CAMD_COST_*
     int saturate;         // U7: 1 = C saturates like OpenCV's CV_SIMD build (default), 0 = wraps like the scalar build
+    int phases;           // CAMD_OPT_PHASES: bit 0 = build the cost volume, bit 1 = aggregate + post (default 3 = both)
     int nbands, nchunks;
     size_t erec_stride;
     unsigned long long* E;
@@ -1174,6 +1175,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     h->band_ok = band_supported(g);
     h->path = 0;
     h->saturate = 1;
+    h->phases = 3;
     h->epoch = 0;
     if (h->band_ok) {
         const int R = BAND_THREADS / g.lanes;
@@ -1277,6 +1279,7 @@ int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
     else if (option == CAMD_OPT_COST && value >= CAMD_COST_AUTO && value <= CAMD_COST_SPLIT) h->cost_path = value;
     else if (option == CAMD_OPT_SATURATE) h->saturate = value != 0;
     else if (option == CAMD_OPT_3WAY_SIMD_LANES && (value == 1 || value == 8)) h->way3_simd_lanes = value;
+    else if (option == CAMD_OPT_PHASES && value >= 1 && value <= 3) h->phases = value;
     else if (option == CAMD_OPT_EXACT) {
         if (value != 0 && !h->Lx && h->may_overflow) {
             // the workspace could not be had when the handle was made: try again rather than stay in refuse mode silently
@@ -1378,8 +1381,9 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     const bool way3 = g.mode == CAMD_MODE_SGBM_3WAY;
     const int vbatch = batch * h->cr.n;  // volumes this call fills (3WAY: four stripes per pair)
     const bool fused = K <= 11 && (h->cost_path != CAMD_COST_SPLIT || way3);
+    const bool do_cost = (h->phases & 1) != 0;
     MARK(ST_COST);
-    if (fused) {
+    if (fused && do_cost) {
         // waves per workgroup: one per 8 disparities, at least 4 (the staging needs up to 3 waves of lanes), at most
         // 8 for RGB (three 8-wave workgroups share a CU at 74 VGPRs: 17.5 instead of 20.2 ms per 64 pairs; a 16-wave
         // workgroup would have a CU to itself) and 16 for gray (fewer registers, and the staging per cell halves)
@@ -1445,7 +1449,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         CAMD_LAUNCH_CHECK();
     }
     MARK(ST_HSUM);
-    if (!fused) {
+    if (!fused && do_cost) {
         int nseg = div_up(g.W1, HSUM_SEG), ndblk = div_up(g.Dp, 64);
         dim3 grid(nseg, g.H, batch), block(64 * ndblk);
         const int es = g.cn == 1 ? 4 : 12;
@@ -1473,7 +1477,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     }
 
     MARK(ST_VSUM);
-    if (!fused) {
+    if (!fused && do_cost) {
         size_t rowv = (size_t)g.W1 * (g.Dp / 8);
         const uint4* hs4 = reinterpret_cast<const uint4*>(h->S);
         uint4* c4 = reinterpret_cast<uint4*>(h->C);
@@ -1498,11 +1502,16 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
     // Volumes that hold a value below P2 are outside the regime of the packed-u16 aggregation kernels (sgbm_exact.hpp).
     // The saturating cost kernel reports them itself; behind the wrapping kernels and the split pair one more pass over
     // C finds them (only where the parameters allow an overflow at all)
-    if (may_overflow && !(fused && sat)) {
+    if (do_cost && may_overflow && !(fused && sat)) {
         if (!fused) CAMD_HIP(hipMemsetAsync(h->cost_neg, 0, (size_t)vbatch * 4, st));
         hipLaunchKernelGGL(k_flag_below, dim3(512, 1, vbatch), dim3(256), 0, st, reinterpret_cast<const int16_t*>(h->C),
                            h->ga, h->vol_elems, h->cr, h->cost_neg);
         CAMD_LAUNCH_CHECK();
+    }
+
+    if (!(h->phases & 2)) {  // CAMD_OPT_PHASES: the caller runs the aggregation in a second call (another stream)
+        for (int i = ST_SCAN; i <= ST_COUNT; i++) MARK(i);
+        return CAMD_OK;
     }
 
     // aggregation path: fused band passes win on throughput (>= ~8 pairs per launch), concurrent

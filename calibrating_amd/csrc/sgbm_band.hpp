@@ -121,6 +121,16 @@ static inline size_t band_erec_stride(int W1, int lanes, int nv) { return (size_
 //                   parabola, store) -- the scalar tail runs with all 64 lanes busy instead of one per group
 // dpk[k] = the two disparities of register k, packed (d | d+1 << 16).
 static constexpr uint32_t WTA_NONE = 0xffffffffu;
+// The parked S vectors of the groups of a wave are read back at [best - 1] / [best + 1] with 2-byte reads (32-bank
+// modulus, two groups per 32-lane half).  At a group stride of LANES * 16 * NV bytes = a multiple of 128 the groups of a
+// half hit the same bank whenever their winners share a dword -- neighbouring rows of a real scene nearly always do
+// (round 4: SQ_LDS_BANK_CONFLICT = 24 % of the LDS-active cycles of the row-parallel pass).  CAMD_WTA_PADQ uint4 of padding
+// per group (WtaPad) move the second group of a half by 16 banks: a conflict then needs winners 32 disparities apart.
+#ifndef CAMD_WTA_PADQ
+#define CAMD_WTA_PADQ 4
+#endif
+// (only where the group stride is a multiple of 128 bytes: 8 or 16 lanes per pixel)
+template <int LANES, int NV> struct WtaPad { static constexpr int Q = (LANES * NV * 16) % 128 == 0 ? CAMD_WTA_PADQ : 0; };
 
 // TIE8: MODE_SGBM_3WAY's winner among equal totals as OpenCV's CV_SIMD build picks it (k_wta, oracle way3_winner),
 // for D % 8 == 0: disparities are scanned 8 at a time, each of the 8 lane slots keeps the LAST d attaining the
@@ -172,7 +182,7 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const
     // park S so that S[best-1], S[best+1] can be picked without a select tree
 #pragma unroll
     for (int v = 0; v < NV; v++)
-        wS[ctid * NV + v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
+        wS[grp * (LANES * NV + WtaPad<LANES, NV>::Q) + li * NV + v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
     // (2) uniqueness: S[d]*(100-u) < minS*100 for some |d-best| > 1
     //     <=>  min over those d of S[d]  <=  T = floor((minS*100 - 1) / (100-u)); the division by the launch
     //     constant 100-u is a multiply-high by floor(2^32/(100-u)) + 1, exact for numerators < 2^32/100
@@ -193,7 +203,7 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const
     const int minfar = (int)(group_min_dup16<LANES>(far) & 0xffffu);
     const bool ok = act && minS < MAX_COST && minfar > T;
     // (3) neighbours for the sub-pixel parabola (same address in every lane of the group: an LDS broadcast)
-    const uint16_t* gs = reinterpret_cast<const uint16_t*>(wS) + (size_t)grp * (LANES * 8 * NV);
+    const uint16_t* gs = reinterpret_cast<const uint16_t*>(wS + grp * (LANES * NV + WtaPad<LANES, NV>::Q));
     const uint32_t Sm = gs[max(best - 1, 0)], Sp = gs[min(best + 1, LANES * 8 * NV - 1)];
     if (li == (t & (LANES - 1))) {
         cap_key = ok ? key : WTA_NONE;
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void
     __shared__ uint4 eD[3][EN];
     __shared__ uint4 eA[3][EN];
     __shared__ uint4 edl[3][FULL ? CPB : 1];
-    __shared__ uint4 wS[MODE == 2 ? BAND_THREADS * NV : 1];  // FINAL: S of the current pixel, per group
+    __shared__ uint4 wS[MODE == 2 ? BAND_THREADS * NV + R * WtaPad<LANES, NV>::Q : 1];  // FINAL: S of the current pixel, per group
     __shared__ uint32_t s_ticket;
 
     if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1u);

@@ -49,8 +49,10 @@ class StereoSGBM:
         'way3_simd_lanes': MODE_SGBM_3WAY's tie rule, 8 = cv2's SSE / NEON builds (default), 1 = scalar build;
         'exact': a pair whose cost volume left the int16 regime of the fast kernels (only after an overflow of the box
         sums on adversarial images) is 1 = aggregated again in plain int arithmetic (default), 0 = refused (written
-        as invalid, status() / the next compute raise)."""
-        opt = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3, "way3_simd_lanes": 4, "exact": 5}[option]
+        as invalid, status() / the next compute raise);
+        'phases': what a compute() call queues, 1 = the cost volume only, 2 = aggregation + post only (on the volume the
+        previous phase-1 call built), 3 = both (default) -- for callers that pipeline the two over two streams."""
+        opt = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3, "way3_simd_lanes": 4, "exact": 5, "phases": 6}[option]
         self._options[opt] = int(value)
         if self._handle is not None:
             _native.check(_native.lib().camd_sgbm_set_option(self._handle, opt, int(value)))
