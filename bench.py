@@ -626,18 +626,20 @@ def main():
         # one-time table broadcast (rank 0 owns the rig), installed into every rank's Stereo; then every rank runs
         # the full get_depth on the SAME two pairs through the broadcast tables and the ranks compare checksums
         t0 = time.perf_counter()
-        rig_dict = synthetic.rig(a.width, a.height)
-        bundle = ca.Stereo.load(rig_dict).table_bundle() if rank == 0 else None
+        # ONLY rank 0 ever sees the rig record; every other rank builds its Stereo from the broadcast alone
+        bundle = ca.Stereo.load(synthetic.rig(a.width, a.height)).table_bundle() if rank == 0 else None
         tables = broadcast_tables(bundle, dev, src=0)
         sync()
         t_bcast = time.perf_counter() - t0
-        stereo = ca.Stereo.load(rig_dict).install_tables(tables, dev)
+        stereo = ca.Stereo.from_bundle(tables, dev)
         if stub:
             # no kernels to run the installed tables through: the checksum is taken over the tables as this rank's
             # Stereo now holds them (what get_depth_batch would read)
             held = stereo._tables(dev)
             dsum = int(sum(torch.nan_to_num(held[k].to(torch.float64)).mul(16).round().to(torch.int64).sum().item()
                            for k in sorted(held)))
+            stereo.set_stereo_matching(StubMatcher(), max_depth=20.0)  # needs cam1.K and t from the parameter block
+            dsum += int(stereo.min_disparity) + int(round(1e6 * stereo.baseline))
             res = imgs = None
         else:
             stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(params, max_size=max(a.width, a.height))),

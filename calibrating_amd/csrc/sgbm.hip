@@ -739,6 +739,7 @@ struct camd_sgbm {
     int16_t* raw;         // [max_batch][H][W] disparity before median
     void* speckle_ws;
     bool speckle_clean;   // every parent entry of speckle_ws is -1 (post.hip keeps it so from call to call)
+    hipStream_t speckle_stream;  // ... by the kernels of the last call, which ran on this stream
     // band-wavefront path (sgbm_band.hpp)
     bool band_ok;         // geometry supported by k_band instantiations
     int path;             // 0 = band passes (default when band_ok), 1 = one k_scan per direction
@@ -1155,8 +1156,15 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         if (e == hipSuccess) e = hipMalloc((void**)&h->C, nvol * h->vol_elems * 2);
         // the padded disparities d >= D of C hold P2 from here on: k_cost's all-padding waves do not write (sgbm_cost.hpp)
         // (complete before the handle is handed out: the first compute may run on a stream the null stream does not order)
-        if (e == hipSuccess) e = hipMemsetD16(h->C, (unsigned short)g.P2, nvol * h->vol_elems);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+        // Only a padded layout has such waves.  The fill runs on a stream of its own and only that stream is waited
+        // for: no device-wide synchronisation, other streams keep running.
+        if (e == hipSuccess && g.Dp != g.D) {
+            hipStream_t fs = nullptr;
+            e = hipStreamCreateWithFlags(&fs, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipMemsetD16Async(h->C, (unsigned short)g.P2, nvol * h->vol_elems, fs);
+            if (e == hipSuccess) e = hipStreamSynchronize(fs);
+            if (fs) (void)hipStreamDestroy(fs);
+        }
         if (e == hipSuccess) e = hipMalloc((void**)&h->S, nvol * h->vol_elems * 2);
         if (e == hipSuccess && way3) e = hipMalloc((void**)&h->rawv, nvol * align_up((size_t)vrows * width * 2, 256));
     }
@@ -1219,12 +1227,17 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
 // what the bits of the device-side error word mean (camd_sgbm_status / the next compute report them)
 static const char* device_error_text(uint32_t e)
 {
-    if (e & 2u)
-        return "a cost volume left the int16 regime of the aggregation kernels (values below P2 after an overflow of the "
-               "box sums) and the handle has no workspace for the exact path; the disparities of that pair were written "
-               "as invalid";
-    return "a band-wavefront pass timed out waiting for its upstream band; the disparities of that call were written as "
-           "invalid";
+    static const char* kRefused =
+        "a cost volume left the int16 regime of the aggregation kernels (values below P2 after an overflow of the box "
+        "sums) and the handle has no workspace for the exact path; the disparities of that pair were written as invalid";
+    static const char* kTimeout =
+        "a band-wavefront pass timed out waiting for its upstream band; the disparities of that call were written as "
+        "invalid";
+    static const char* kBoth =
+        "a band-wavefront pass timed out waiting for its upstream band (the disparities of that call were written as "
+        "invalid) AND a cost volume left the int16 regime of the aggregation kernels with no workspace for the exact "
+        "path (that pair was written as invalid)";
+    return (e & 3u) == 3u ? kBoth : ((e & 2u) ? kRefused : kTimeout);
 }
 
 int camd_sgbm_destroy(camd_sgbm* h)
@@ -1660,6 +1673,9 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         if (rc != CAMD_OK) return rc;
         MARK(ST_SPECKLE);
         if (g.speckleWindowSize > 0) {
+            // the "workspace is clean" invariant is established by the previous call's k_cc_apply, in stream order: a call
+            // on another stream is not ordered behind it, so it clears the workspace itself (on its own stream)
+            if (h->speckle_stream != st) { h->speckle_clean = false; h->speckle_stream = st; }
             rc = launch_speckle(disp, dpe, dse, g.W, g.H, (g.minD - 1) * 16, g.speckleWindowSize,
                                 16 * g.speckleRange, h->speckle_ws, speckle_ws_bytes(g.W, g.H, h->max_batch), batch, st,
                                 &h->speckle_clean);

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void
             while (!dead && __hip_atomic_load(Fin + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
                 __builtin_amdgcn_s_sleep(4);
                 if (++spins > BAND_SPIN_LIMIT) {
-                    atomicExch(a.err, 1u);
+                    atomicOr(a.err, 1u);  // bit 0; bit 1 (a refused pair, k_poison_flagged) must survive
                     dead = true;
                 }
             }

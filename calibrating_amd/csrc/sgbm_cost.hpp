@@ -365,6 +365,9 @@ __global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t*
                         ovf_max = pk_max_u16(pk_max_u16(ovf_max, pk_max_u16(acc[0], acc[1])), pk_max_u16(acc[2], acc[3]));
                 }
                 // entries of row r+1 from the rows fetched one step ago; then fetch for row r+2
+#if defined(CAMD_COST_DBG_NOSTAGE) && !defined(CAMD_MEASUREMENT_BUILD)
+#error "CAMD_COST_DBG_NOSTAGE produces wrong results: measurement builds only (define CAMD_MEASUREMENT_BUILD too)"
+#endif
 #ifndef CAMD_COST_DBG_NOSTAGE  // (measurement only: what the staging costs; the results are wrong without it)
                 stage_entries((r + 1) & 1);
                 fetch_rows(row_of(r + 2));

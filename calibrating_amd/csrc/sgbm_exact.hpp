@@ -26,8 +26,20 @@ __global__ __launch_bounds__(256) void k_flag_below(const int16_t* __restrict__ 
     const uint4* p = reinterpret_cast<const uint4*>(C + (size_t)vp * vol_stride);
     const uint32_t thr = dup16((uint32_t)g.P2);
     bool below = false;
+    const int dq = g.Dp / 8;  // uint4 per pixel
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
-        const uint4 q = p[i];  // padded d >= D hold exactly P2 (k_cost, k_vsum), never less
+        uint4 q = p[i];
+        // padded d >= D are expected to hold P2, but nothing here depends on it: they are replaced by the threshold
+        const int d0 = (int)(i % (size_t)dq) * 8;
+        if (d0 + 8 > g.D) {
+            uint32_t* w = &q.x;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int d = d0 + 2 * k;
+                if (d >= g.D) w[k] = thr;
+                else if (d + 1 >= g.D) w[k] = (w[k] & 0xffffu) | (thr & 0xffff0000u);
+            }
+        }
         const s16x2_t t = __builtin_bit_cast(s16x2_t, thr);
         const s16x2_t m = __builtin_elementwise_min(
             __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, q.x), __builtin_bit_cast(s16x2_t, q.y)),

@@ -8,6 +8,11 @@ additionally moves each result on a side stream as soon as its kernel has been q
 results (the rectified images) run underneath the later kernels (SGBM).  At 1080p the ~60 MB a ``get_depth`` call
 returns cost more wall time through pageable copies than all of its kernels.
 
+Inputs are NOT staged: a pageable ``.cuda()`` of a 1080p RGB image takes 0.12 ms on the GPU box (50 GB/s), while a
+fresh page-locked block per call costs 1.6 ms and two in a row 9.8 ms whenever the first is still in flight
+(tools/microtests/upload_probe.py, profiles/r05_upload_probe.txt) -- the asymmetry to the results is that those are
+large, many, and produced at different times.
+
 ``PINNED = False`` falls back to plain ``.cpu()`` copies (for hosts where page-locked memory is rationed); whatever a
 call returns beyond ``PINNED_MAX_BYTES`` takes plain copies by itself (``to_host`` and ``Sink`` alike).
 Ownership: every returned ndarray owns its page-locked block for as long as it lives (about 60 MB per 1080p

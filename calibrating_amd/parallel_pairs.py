@@ -1,9 +1,9 @@
 """Multi-GPU layer of the stereo path: independent pairs shard across ranks, tables are broadcast once.
 
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the
-CPU tests).  There is no per-pair communication: a rig's remap tables / validity mask (~35 MB at
-1080p) are broadcast from rank 0 once and installed into every rank's ``Stereo``
-(``Stereo.install_tables``), then every rank runs ``Stereo.get_depth_batch`` / ``StereoSGBM.compute``
+CPU tests).  There is no per-pair communication: a rig's table bundle (six float32 maps, the validity
+mask and a 64-double parameter block: ~52 MB at 1080p) is broadcast from rank 0 once and every other rank
+builds its ``Stereo`` from it alone (``Stereo.from_bundle``: a worker never sees the rig record), then every rank runs ``Stereo.get_depth_batch`` / ``StereoSGBM.compute``
 on its contiguous shard of the pair list.  ``bench.py`` is built from the
 functions of this module, so the world_size-2 gloo test exercises the same code the RCCL run does.
 """
@@ -23,7 +23,7 @@ def owner_of(pair_index, n_pairs, world_size):
     return pair_index * world_size // n_pairs
 
 
-_BUNDLE_KEYS = ("map1x", "map1y", "map2x", "map2y", "mask")
+_BUNDLE_KEYS = ("map1x", "map1y", "map2x", "map2y", "mask", "unrect_mapx", "unrect_mapy", "params")
 
 
 def broadcast_tables(bundle, device, src=0):
@@ -31,25 +31,27 @@ def broadcast_tables(bundle, device, src=0):
 
     ``bundle`` is the dict on ``src`` and ignored (may be None) elsewhere.  Shapes travel first in one
     small int64 tensor, then one collective per table.  Returns a dict of tensors on ``device``
-    (feed it to ``Stereo.install_tables``).
+    (feed it to ``Stereo.from_bundle``, or to ``Stereo.install_tables`` of a rig built from the record).
     """
     import torch
     import torch.distributed as dist
     rank = dist.get_rank()
-    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    # shapes first: (h, w) of the rectified frame and of camera 1's frame (the unrectify maps live there)
+    meta = torch.zeros(4, dtype=torch.int64, device=device)
     if rank == src:
-        h, w = bundle["map1x"].shape
-        meta[0], meta[1] = h, w
+        meta[0], meta[1] = bundle["map1x"].shape
+        meta[2], meta[3] = bundle["unrect_mapx"].shape
     dist.broadcast(meta, src=src)
-    h, w = int(meta[0].item()), int(meta[1].item())
+    hw, hw1 = (int(meta[0].item()), int(meta[1].item())), (int(meta[2].item()), int(meta[3].item()))
     out = {}
     for k in _BUNDLE_KEYS:
-        dtype = torch.uint8 if k == "mask" else torch.float32
+        dtype = torch.uint8 if k == "mask" else (torch.float64 if k == "params" else torch.float32)
+        shape = (64,) if k == "params" else (hw1 if k.startswith("unrect_") else hw)
         if rank == src:
             t = torch.from_numpy(np.ascontiguousarray(bundle[k])).to(device)
-            assert t.dtype == dtype and tuple(t.shape) == (h, w)
+            assert t.dtype == dtype and tuple(t.shape) == shape, (k, t.dtype, tuple(t.shape))
         else:
-            t = torch.empty((h, w), dtype=dtype, device=device)
+            t = torch.empty(shape, dtype=dtype, device=device)
         dist.broadcast(t, src=src)
         out[k] = t
     return out

@@ -6,6 +6,7 @@ Mirrors the part of cv2's interface the reference touches
 ``compute`` takes NumPy arrays (host path: one H2D + one D2H copy) or torch CUDA tensors
 (zero-copy) and also accepts a leading batch dimension, which cv2 does not.
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -27,6 +28,15 @@ _DEFAULTS = dict(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, dis
 
 
 class StereoSGBM:
+    # A handle owns the device workspace for one (width, height, channels, device) and a maximum batch.  cv2's object
+    # takes any image size from call to call (stereo_matching.py:63 feeds it whatever the resize produced), so the
+    # handles of the last few shapes are kept (least recently used first out) instead of paying a multi-GB
+    # hipFree + hipMalloc whenever two sizes alternate.  Bounded by a count and by a byte budget
+    # (camd_sgbm_workspace_bytes; None = half of the device's memory); the handle in use is never evicted.
+    HANDLE_CACHE = 4
+    HANDLE_CACHE_BYTES = None
+    creates = 0  # camd_sgbm_create calls of this process (tests / latency measurements read it)
+
     def __init__(self, **kw):
         self._p = dict(_DEFAULTS)
         for k, v in kw.items():
@@ -35,6 +45,8 @@ class StereoSGBM:
             self._p[k] = int(v)
         self._handle = None
         self._key = None
+        self._max_batch = 0
+        self._cache = collections.OrderedDict()  # key -> (handle, max_batch, workspace bytes)
         self.profiling = False
         self._options = {}
 
@@ -54,15 +66,14 @@ class StereoSGBM:
         previous phase-1 call built), 3 = both (default) -- for callers that pipeline the two over two streams."""
         opt = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3, "way3_simd_lanes": 4, "exact": 5, "phases": 6}[option]
         self._options[opt] = int(value)
-        if self._handle is not None:
-            _native.check(_native.lib().camd_sgbm_set_option(self._handle, opt, int(value)))
+        for hd, _, _ in self._cache.values():
+            _native.check(_native.lib().camd_sgbm_set_option(hd, opt, int(value)))
         return self
 
     def status(self):
         """Synchronise and raise if a device-side bounded wait timed out (fused path)."""
-        if self._handle is not None:
-            _native.check(_native.lib().camd_sgbm_status(self._handle, _native.current_stream()),
-                          "StereoSGBM")
+        for hd, _, _ in list(self._cache.values()):
+            _native.check(_native.lib().camd_sgbm_status(hd, _native.current_stream()), "StereoSGBM")
 
     # -- cv2-style accessors ---------------------------------------------------------------------
     def _get(self, k):
@@ -101,10 +112,12 @@ class StereoSGBM:
 
     # -- handle management -----------------------------------------------------------------------
     def _release(self):
-        if self._handle is not None:
-            _native.lib().camd_sgbm_destroy(self._handle)
-            self._handle = None
-            self._key = None
+        for hd, _, _ in self._cache.values():
+            _native.lib().camd_sgbm_destroy(hd)
+        self._cache.clear()
+        self._handle = None
+        self._key = None
+        self._max_batch = 0
 
     def __del__(self):
         try:
@@ -115,20 +128,41 @@ class StereoSGBM:
     def _cparams(self):
         return _native.SgbmParams(**self._p)
 
+    def _budget(self, device_index):
+        if self.HANDLE_CACHE_BYTES is not None:
+            return self.HANDLE_CACHE_BYTES
+        import torch
+        return torch.cuda.get_device_properties(device_index).total_memory // 2
+
     def _ensure(self, w, h, cn, batch, device_index):
         key = (w, h, cn, device_index)
-        if self._handle is not None and self._key == key and self._max_batch >= batch:
+        hit = self._cache.get(key)
+        if hit is not None and hit[1] >= batch:
+            self._cache.move_to_end(key)
+            self._handle, self._key, self._max_batch = hit[0], key, hit[1]
             return
-        self._release()
-        hd = ctypes.c_void_p()
+        lib = _native.lib()
+        if hit is not None:  # same shape, larger batch: the smaller workspace goes first
+            lib.camd_sgbm_destroy(self._cache.pop(key)[0])
+            self._handle = None
         p = self._cparams()
-        _native.check(_native.lib().camd_sgbm_create(ctypes.byref(p), w, h, cn, batch, ctypes.byref(hd)),
-                      "StereoSGBM")
+        need = int(lib.camd_sgbm_workspace_bytes(ctypes.byref(p), w, h, cn, batch))
+        # make room BEFORE allocating: least recently used first, until count and bytes fit with the new handle
+        budget = self._budget(device_index)
+        while self._cache and (len(self._cache) >= self.HANDLE_CACHE
+                               or sum(v[2] for v in self._cache.values()) + need > budget):
+            _, (old, _, _) = self._cache.popitem(last=False)
+            lib.camd_sgbm_destroy(old)
+        self._handle = None
+        hd = ctypes.c_void_p()
+        _native.check(lib.camd_sgbm_create(ctypes.byref(p), w, h, cn, batch, ctypes.byref(hd)), "StereoSGBM")
+        StereoSGBM.creates += 1
+        self._cache[key] = (hd, batch, need)
         self._handle, self._key, self._max_batch = hd, key, batch
         if self.profiling:
-            _native.check(_native.lib().camd_sgbm_set_profiling(self._handle, 1))
+            _native.check(lib.camd_sgbm_set_profiling(hd, 1))
         for opt, val in self._options.items():
-            _native.check(_native.lib().camd_sgbm_set_option(self._handle, opt, val))
+            _native.check(lib.camd_sgbm_set_option(hd, opt, val))
 
     def workspace_bytes(self, w, h, cn=1, batch=1):
         p = self._cparams()
@@ -207,8 +241,8 @@ class StereoSGBM:
 
     def set_profiling(self, enable=True):
         self.profiling = bool(enable)
-        if self._handle is not None:
-            _native.check(_native.lib().camd_sgbm_set_profiling(self._handle, int(self.profiling)))
+        for hd, _, _ in self._cache.values():
+            _native.check(_native.lib().camd_sgbm_set_profiling(hd, int(self.profiling)))
 
     def stage_times_ms(self):
         """{stage: ms} of the last compute (hipEvents on the compute stream)."""

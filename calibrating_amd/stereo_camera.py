@@ -25,6 +25,11 @@ from .camera import Cam, read_record, write_record
 from .stereo_matching import SemiGlobalBlockMatching
 
 _TABLE_KEYS = ("map1x", "map1y", "map2x", "map2y", "mask")
+# A broadcast bundle: the six float32 maps, the validity mask and a block of 64 doubles
+# from which a worker rank builds its rig without ever seeing the rig record.
+_BUNDLE_MAGIC = 20250930.0
+_P = dict(magic=(0, 1), K=(1, 10), R1=(10, 19), R2=(19, 28), cam1_K=(28, 37), cam1_D=(37, 51), cam1_xy=(51, 53),
+          cam2_xy=(53, 55), xy=(55, 57), t=(57, 60), nD=(60, 61))
 
 
 class Stereo:
@@ -67,7 +72,14 @@ class Stereo:
 
     def _host_table(self, name, build):
         if name not in self._host:
-            self._host[name] = build()
+            if getattr(self, "_bundle_only", False):  # no camera 2 intrinsics to rebuild from: the installed tensors
+                tb = next(v for k, v in self._dev.items() if isinstance(v, dict))
+                un = next(v for k, v in self._dev.items() if k.startswith("unrect:"))
+                host = lambda t: t.cpu().numpy()  # noqa: E731
+                self._host.update(map1=(host(tb["map1x"]), host(tb["map1y"])), map2=(host(tb["map2x"]), host(tb["map2y"])),
+                                  mask1=host(tb["mask"]).astype(bool), unrect=(host(un[0]), host(un[1])))
+            else:
+                self._host[name] = build()
         return self._host[name]
 
     @property
@@ -100,9 +112,25 @@ class Stereo:
         return self._dev[key]
 
     def table_bundle(self):
-        """Host copies of everything a worker rank needs (parallel_pairs.broadcast_tables sends this)."""
+        """Host copies of everything a worker rank needs (parallel_pairs.broadcast_tables sends this): the rectify
+        maps of both cameras, the validity mask, the unrectify maps (utils.py:183-191, memoised by the reference in
+        ``_unrectify_depth_maps``) and ``params``: 64 float64 -- K, R1, R2, cam1.K, cam1.D, the three image sizes and t
+        (what :159-176,408-431,466-489 read).  ~52 MB at 1080p.  ``Stereo.from_bundle`` is the receiving side."""
         (m1x, m1y), (m2x, m2y) = self.undistort_rectify_map1, self.undistort_rectify_map2
-        return dict(map1x=m1x, map1y=m1y, map2x=m2x, map2y=m2y, mask=self.rectify_valid_mask1.view(np.uint8))
+        ux, uy = self._host_table("unrect", lambda: geometry.init_undistort_rectify_map(
+            self.K, None, self.R1.T, self.cam1.K, self.cam1.xy))
+        p = np.zeros(64)
+        d = np.asarray(self.cam1.D, np.float64).reshape(-1)
+        if d.size > 14:
+            raise ValueError("camera 1 has %d distortion coefficients; the bundle carries up to 14" % d.size)
+        for name, val in (("magic", _BUNDLE_MAGIC), ("K", self.K), ("R1", self.R1), ("R2", self.R2), ("cam1_K", self.cam1.K),
+                          ("cam1_xy", self.cam1.xy), ("cam2_xy", self.cam2.xy), ("xy", self.xy), ("t", self.t),
+                          ("nD", d.size)):
+            lo, hi = _P[name]
+            p[lo:hi] = np.asarray(val, np.float64).reshape(-1)
+        p[_P["cam1_D"][0]:_P["cam1_D"][0] + d.size] = d
+        return dict(map1x=m1x, map1y=m1y, map2x=m2x, map2y=m2y, mask=self.rectify_valid_mask1.view(np.uint8),
+                    unrect_mapx=ux, unrect_mapy=uy, params=p)
 
     def install_tables(self, bundle, device=None):
         """Use the tensors of a broadcast table bundle (parallel_pairs.broadcast_tables) as this rig's device
@@ -115,7 +143,34 @@ class Stereo:
             raise ValueError("bundle is for a %dx%d rectified image, this rig rectifies to %dx%d" % (w, h, *self.xy))
         device = bundle["map1x"].device if device is None else device
         self._dev[str(device)] = {k: bundle[k] for k in _TABLE_KEYS}
+        if "unrect_mapx" in bundle:
+            self._dev["unrect:" + str(device)] = (bundle["unrect_mapx"], bundle["unrect_mapy"])
         return self
+
+    @classmethod
+    def from_bundle(cls, bundle, device=None):
+        """A rig built from a broadcast bundle ALONE -- no record, no rebuild: what a worker rank of a multi-GPU job
+        holds.  It serves everything ``get_depth`` / ``get_depth_batch`` touch (tables from the bundle; K, R1, t,
+        cam1.K / D / xy from ``params``); camera 2's intrinsics and the rig's R are not part of a bundle (nothing on
+        the depth path reads them once the maps exist), so ``dump`` and a rebuild for another target frame need the
+        record."""
+        p = bundle["params"]
+        p = np.asarray(p.cpu() if hasattr(p, "cpu") else p, np.float64).reshape(-1)
+        if p.size != 64 or p[0] != _BUNDLE_MAGIC:
+            raise ValueError("not a table bundle of this version (params block: %d doubles, magic %r)" % (p.size, p[:1]))
+        get = lambda name: p[_P[name][0]:_P[name][1]]  # noqa: E731
+        nD = int(get("nD")[0])
+        xy_of = lambda name: tuple(int(v) for v in get(name))  # noqa: E731
+        st = cls(xy_target=list(xy_of("xy")), K_target=get("K").reshape(3, 3).copy())
+        st.cam1 = Cam(get("cam1_K").reshape(3, 3).copy(), get("cam1_D")[:nD].reshape(1, -1).copy() if nD else None,
+                      xy_of("cam1_xy"), name="cam1 (from a table bundle)")
+        st.cam2 = Cam(np.full((3, 3), np.nan), None, xy_of("cam2_xy"), name="cam2 (maps only: from a table bundle)")
+        st.t = get("t").reshape(3, 1).copy()
+        st.R1, st.R2 = get("R1").reshape(3, 3).copy(), get("R2").reshape(3, 3).copy()
+        st.K, st.xy = get("K").reshape(3, 3).copy(), xy_of("xy")
+        st._host, st._dev = {}, {}
+        st._bundle_only = True
+        return st.install_tables(bundle, device)
 
     # ---- record I/O --------------------------------------------------------------------------------
     def dump(self, path="", return_dict=False):
@@ -223,6 +278,8 @@ class Stereo:
     def _to_dev(img):
         import torch
         if isinstance(img, np.ndarray):
+            # (a plain pageable copy: 0.12 ms per 1080p image on the GPU box; staging through a page-locked block
+            # was measured 10x slower, see hostio)
             return torch.from_numpy(np.ascontiguousarray(img)).cuda(), True
         return img, False
 
@@ -303,30 +360,52 @@ class Stereo:
             return imgproc.disp16_resized_to_depth(disp16, hw, *args)
         return imgproc.disp_to_depth(disp16, *args)
 
-    def get_depth(self, img1, img2, return_unrectify_depth=True, return_distort_depth=False):
+    RESULT_KEYS = ("rectify_img1", "rectify_img2", "disparity", "rectify_depth", "unrectify_depth", "undistort_img1")
+
+    def get_depth(self, img1, img2, return_unrectify_depth=True, return_distort_depth=False, keys=None):
         """Return dict: rectify_img1, rectify_depth, disparity, rectify_img2 (+ unrectify_depth,
         undistort_img1). Depth unit is m; 0 = invalid.  ndarray inputs give ndarray results (each result starts
-        its way to the host as soon as its kernel is queued, hostio.Sink); device tensors stay on the device."""
+        its way to the host as soon as its kernel is queued, hostio.Sink); device tensors stay on the device.
+
+        ``keys`` (not in the reference): the entries the caller wants, e.g. ``keys=("unrectify_depth",)``.  The full
+        dict of a 1080p pair is ~60 MB -- two float64 depth maps among them -- and its way back over PCIe costs as much
+        as a third of the kernels; entries that are not asked for are neither copied nor, where nothing else needs
+        them (undistort_img1, unrectify_depth), computed.  ``None`` = the reference's dict."""
         import torch
         assert hasattr(self, "stereo_matching"), "Please stereo.set_stereo_matching(stereo_matching)"
         if return_distort_depth:
             self.distort_depth(None)
-        i1, was_np = self._to_dev(self._get_img(img1))
-        i2, _ = self._to_dev(self._get_img(img2))
-        sink = hostio.Sink(i1.device) if was_np else None
-        result = {}
+        if keys is not None:
+            keys = (keys,) if isinstance(keys, str) else tuple(keys)
+            unknown = [k for k in keys if k not in self.RESULT_KEYS]
+            if unknown:
+                raise ValueError("get_depth(keys=...): unknown result entries %s (known: %s)" % (unknown, list(self.RESULT_KEYS)))
+            return_unrectify_depth = "unrectify_depth" in keys or "undistort_img1" in keys
+        want = (lambda k: True) if keys is None else (lambda k: k in keys)
+        img1, img2 = self._get_img(img1), self._get_img(img2)
+        was_np = isinstance(img1, np.ndarray)
+        sink, result = None, {}
 
         def emit(**tensors):
-            result.update(tensors)
-            if sink is not None:
-                for k, t in tensors.items():
-                    sink.send(k, t)
+            for k, t in tensors.items():
+                if want(k):
+                    result[k] = t
+                    if sink is not None:
+                        sink.send(k, t)
 
-        rectify_img1, rectify_img2 = self.rectify(i1, i2)
-        emit(rectify_img1=rectify_img1, rectify_img2=rectify_img2)
-        if return_unrectify_depth:
-            emit(undistort_img1=self.undistort_img(i1))  # independent of the matcher: its copy hides under SGBM
+        # camera 1 first: its rectification and undistortion are queued before camera 2's pixels are copied
+        i1, _ = self._to_dev(img1)
+        if was_np:
+            sink = hostio.Sink(i1.device)
         tb = self._tables(i1.device)
+        rectify_img1 = imgproc.remap(i1, tb["map1x"], tb["map1y"], imgproc.INTER_LANCZOS4)
+        emit(rectify_img1=rectify_img1)
+        if return_unrectify_depth and want("undistort_img1"):
+            emit(undistort_img1=self.undistort_img(i1))  # independent of the matcher: its copy hides under SGBM
+        i2, _ = self._to_dev(img2)
+        shift = self.min_disparity if getattr(self, "translation_rectify_img", None) else 0
+        rectify_img2 = imgproc.remap(i2, tb["map2x"], tb["map2y"], imgproc.INTER_LANCZOS4, x_shift=shift)
+        emit(rectify_img2=rectify_img2)
         plugin = self.stereo_matching
         sm = self._sgbm_full_res(rectify_img1.shape[:2])
         if sm is not None:
@@ -347,9 +426,11 @@ class Stereo:
                 disparity = torch.from_numpy(np.ascontiguousarray(disparity)).to(i1.device)
             disparity = tb["mask"].to(torch.bool) * disparity
             rectify_depth = self.disparity_to_depth(disparity)
+        if return_unrectify_depth and want("unrectify_depth"):
+            # queued before the copies of disparity / rectify_depth start: the caller usually waits for this one
+            unrect = self.unrectify_depth(rectify_depth)
+            emit(unrectify_depth=unrect)
         emit(disparity=disparity, rectify_depth=rectify_depth)
-        if return_unrectify_depth:
-            emit(unrectify_depth=self.unrectify_depth(rectify_depth))
         if sink is not None:
             result.update(sink.collect())
             if isinstance(plugin, SemiGlobalBlockMatching):

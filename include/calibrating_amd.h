@@ -5,8 +5,12 @@
  * Every entry point replaces one native (cv2 / NumPy) call the reference makes on that path; the
  * file:line after "replaces" points into /root/reference/calibrating/.  All image / volume pointers
  * are DEVICE pointers unless the name ends in `_host`; `stream` is a hipStream_t passed as void*
- * (NULL = the default stream).  Launches are asynchronous on `stream`; nothing here calls
- * hipDeviceSynchronize.  Return value: 0 on success, a negative camd_status otherwise;
+ * (NULL = the default stream).  Launches are asynchronous on `stream`; the compute entry points never synchronise the
+ * device or a stream (camd_sgbm_status and the data-dependent count of camd_depth_to_point_cloud's caller excepted).
+ * The init-time calls camd_sgbm_create / camd_sgbm_destroy / camd_sgbm_set_option(CAMD_OPT_PATH, CAMD_PATH_CONCURRENT)
+ * allocate and free device memory (hipMalloc / hipFree synchronise implicitly) and are not for stream capture;
+ * camd_sgbm_create fills the padding of its cost volume on a private stream and waits for that stream only.
+ * Return value: 0 on success, a negative camd_status otherwise;
  * camd_last_error() then holds a message (thread-local).
  *
  * Handles are not thread-safe: use one handle per host thread / stream.

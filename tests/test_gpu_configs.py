@@ -86,7 +86,7 @@ def test_c3_sharding_invariance():
 
 def test_rccl_path_with_one_forced_rank():
     """bench.py's distributed branch on the GPU under torch.distributed.run with ONE rank: init_process_group("nccl")
-    (= RCCL), table broadcast, Stereo.install_tables, barrier-bracketed timing, all_gather of the results and the
+    (= RCCL), table broadcast, Stereo.from_bundle, barrier-bracketed timing, all_gather of the results and the
     cross-rank checksum agreement -- everything the multi-GPU run does except having a second device."""
     import json
     import os
@@ -104,5 +104,30 @@ def test_rccl_path_with_one_forced_rank():
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["rccl"]["backend"].startswith("nccl") and d["rccl"]["ranks_agree"] is True
-    assert d["rccl"]["table_bytes"] == 4 * 4 * 640 * 360 + 640 * 360
+    assert d["rccl"]["table_bytes"] == 6 * 4 * 640 * 360 + 640 * 360 + 64 * 8  # 6 maps + mask + 64 doubles
     assert d["value"] > 0 and d["rccl"]["per_rank"][0]["pairs"] == 16
+
+
+def test_rig_from_a_table_bundle_alone_equals_the_rig_from_the_record():
+    """What a worker rank of a multi-GPU job holds: ``Stereo.from_bundle`` of the broadcast tensors (6 maps + mask +
+    64 doubles), never the rig record.  Its get_depth / get_depth_batch -- incl. undistort_img1, whose maps it builds
+    from cam1.K / cam1.D of the parameter block -- must return the record-built rig's bits."""
+    W, H = 448, 336
+    rec = synthetic.rig(W, H)
+    dev = torch.device("cuda", 0)
+    cfg = dict(max_size=W, minDisparity=0, numDisparities=64, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+               uniquenessRatio=10, speckleWindowSize=60, speckleRange=2)
+    full = ca.Stereo.load(rec)
+    bundle = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in full.table_bundle().items()}
+    assert sum(t.numel() * t.element_size() for t in bundle.values()) == W * H * 25 + 512
+    worker = ca.Stereo.from_bundle(bundle, dev)
+    for st in (full, worker):
+        st.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=3.5)
+    img1, img2, _ = synthetic.render_plane_pair(rec, (0.2, 0.1, 1.0), 2.0)
+    want, got = full.get_depth(img1, img2), worker.get_depth(img1, img2)
+    assert sorted(want) == sorted(got)
+    for k in want:
+        assert np.array_equal(want[k], got[k]), k
+    assert (got["unrectify_depth"] > 0).mean() > 0.3
+    gb = worker.get_depth_batch(np.stack([img1, img1]), np.stack([img2, img2]))
+    assert all(np.array_equal(gb[k][1], want[k]) for k in want)

@@ -223,6 +223,36 @@ def test_u7_two_stage_build_flags_only_the_saturating_pairs(oracle):
         assert np.array_equal(_c_volume(m, i), vols[i]), i
 
 
+def test_cost_paths_switched_on_one_handle_with_padded_disparities(oracle):
+    """ONE handle, the reference's default matcher parameters (block 11 x RGB: an int16 overflow is possible, so the
+    below-P2 flags are live; D = 218 padded to 256), switched between the fused cost kernel, the split pair, the
+    saturating and the wrapping build from call to call.  The padded disparities of the cost volume are expected to
+    hold P2 whichever kernel wrote the volume last (k_cost's all-padding waves write nothing; k_flag_below no longer
+    depends on it): no pair may be flagged, refused or come back different."""
+    H, W, D = 40, 300, 218
+    p = dict(minDisparity=2, numDisparities=D, blockSize=11, P1=968, P2=3872, disp12MaxDiff=0, uniquenessRatio=5,
+             speckleWindowSize=200, speckleRange=2)
+    a = synthetic.rectified_pair(seed=21, H=H, W=W + 60, D=64, cn=3)
+    b = synthetic.rectified_pair(seed=22, H=H, W=W + 60, D=64, cn=3)
+    want = [oracle.sgbm_compute(l, r, **p) for l, r in (a, b)]
+    m = ca.StereoSGBM_create(**p)
+    m.set_option("exact", 0)  # a wrongly raised flag must surface as a refusal, not be repaired silently
+    seq = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 1), (2, 1), (0, 1)]
+    for i, (cost, sat) in enumerate(seq):
+        m.set_option("cost", cost).set_option("saturate", sat)
+        l, r = (a, b)[i & 1]
+        got = m.compute(l, r)
+        m.status()
+        assert np.array_equal(got, want[i & 1]), (i, cost, sat)
+        vol = m.debug_volume("C").cpu().numpy()
+        assert vol.shape[-1] == D and vol.min() >= p["P2"]
+    # and as a batch of both pairs through the band passes
+    m.set_option("path", 2)
+    got = m.compute(np.stack([a[0], b[0]]), np.stack([a[1], b[1]]))
+    m.status()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
 def test_u7_modes_agree_without_overflow(oracle):
     """Block 11 x RGB on black/white and checkerboard images (the reference's default block size): no window sum
     reaches 32767, so saturate and wrap give the same disparity, equal to the oracle's."""
@@ -301,3 +331,26 @@ def test_get_depth_is_capturable_in_a_hip_graph():
     for k in want:
         assert torch.equal(got[k], want[k]), k
     assert not torch.equal(want["disparity"], ref["disparity"])
+
+
+def test_get_depth_keys_returns_the_asked_entries_only():
+    """``get_depth(..., keys=...)`` (not in the reference: its dict is ~60 MB per 1080p pair) returns exactly the asked
+    entries, each identical to the full dict's; entries nothing else needs are not even computed."""
+    W, H = 320, 240
+    rec = synthetic.rig(W, H)
+    stereo = ca.Stereo.load(rec)
+    cfg = dict(max_size=W, minDisparity=0, numDisparities=64, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+               uniquenessRatio=10, speckleWindowSize=50, speckleRange=2)
+    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=3.5)
+    img1, img2, _ = synthetic.render_plane_pair(rec, (0.2, 0.1, 1.0), 2.0)
+    full = stereo.get_depth(img1, img2)
+    assert sorted(full) == sorted(ca.Stereo.RESULT_KEYS)
+    for keys in (("unrectify_depth",), ("rectify_depth", "disparity"), "undistort_img1", ca.Stereo.RESULT_KEYS):
+        got = stereo.get_depth(img1, img2, keys=keys)
+        want_keys = (keys,) if isinstance(keys, str) else keys
+        assert sorted(got) == sorted(want_keys)
+        assert all(isinstance(v, np.ndarray) and np.array_equal(v, full[k]) for k, v in got.items())
+    t = stereo.get_depth(torch.from_numpy(img1).cuda(), torch.from_numpy(img2).cuda(), keys=("unrectify_depth",))
+    assert list(t) == ["unrectify_depth"] and np.array_equal(t["unrectify_depth"].cpu().numpy(), full["unrectify_depth"])
+    with pytest.raises(ValueError):
+        stereo.get_depth(img1, img2, keys=("depth",))

@@ -7,6 +7,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+import calibrating_amd as ca  # noqa: E402
 from calibrating_amd import StereoSGBM_create, synthetic  # noqa: E402
 
 
@@ -198,3 +199,41 @@ def test_c_abi_handle_sized_for_more_pairs_than_the_first_call(oracle):
                 assert np.array_equal(out[i].cpu().numpy(), want[i]), (n, i)
     finally:
         _native.check(lib.camd_sgbm_destroy(hd))
+
+
+def test_matcher_keeps_a_handle_per_image_shape(oracle):
+    """cv2's StereoSGBM object takes any image size from call to call (the reference's plugin feeds it whatever its
+    resize produced, stereo_matching.py:60-63).  One matcher alternating between two shapes must not rebuild its device
+    workspace every call: after the first call of each shape no camd_sgbm_create happens, the results stay identical,
+    and the cache is bounded (least recently used out)."""
+    p = dict(minDisparity=0, numDisparities=64, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, uniquenessRatio=10)
+    a = synthetic.rectified_pair(seed=1, H=120, W=320, D=64, cn=3)   # "640 x 480" / "800 x 600" in small
+    b = synthetic.rectified_pair(seed=2, H=150, W=400, D=64, cn=3)
+    want = [oracle.sgbm_compute(*a, **p), oracle.sgbm_compute(*b, **p)]
+    m = ca.StereoSGBM_create(**p)
+    m.compute(*a)
+    m.compute(*b)
+    n0 = ca.StereoSGBM.creates
+    for k in range(6):
+        pair, w = ((a, want[0]), (b, want[1]))[k & 1]
+        assert np.array_equal(m.compute(*pair), w)
+    assert ca.StereoSGBM.creates == n0, "alternating two shapes re-created a handle"
+    # a larger batch of a known shape replaces that shape's handle (one create), then serves the smaller batches too
+    m.compute(np.stack([a[0], a[0]]), np.stack([a[1], a[1]]))
+    assert ca.StereoSGBM.creates == n0 + 1
+    assert np.array_equal(m.compute(*a), want[0]) and ca.StereoSGBM.creates == n0 + 1
+    # bounded: more shapes than HANDLE_CACHE evicts the least recently used, never the one in use
+    for k in range(ca.StereoSGBM.HANDLE_CACHE + 1):
+        c = synthetic.rectified_pair(seed=3, H=64, W=200 + 16 * k, D=64, cn=3)
+        assert np.array_equal(m.compute(*c), oracle.sgbm_compute(*c, **p))
+    assert len(m._cache) == ca.StereoSGBM.HANDLE_CACHE
+    # a byte budget below two handles keeps only the one in use
+    m2 = ca.StereoSGBM_create(**p)
+    m2.HANDLE_CACHE_BYTES = 1
+    m2.compute(*a)
+    m2.compute(*b)
+    assert len(m2._cache) == 1 and np.array_equal(m2.compute(*a), want[0])
+    # a parameter change drops every handle (cv2 setters take effect on the next compute)
+    m.setUniquenessRatio(5)
+    assert len(m._cache) == 0
+    assert np.array_equal(m.compute(*a), oracle.sgbm_compute(*a, **dict(p, uniquenessRatio=5)))

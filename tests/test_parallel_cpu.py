@@ -26,14 +26,33 @@ def _worker(rank, world, port, q):
         from calibrating_amd import synthetic
         from calibrating_amd.parallel_pairs import aggregate, broadcast_tables, ranks_agree, shard_range, timed_steps
         bundle = None
-        if rank == 0:
-            bundle = ca.Stereo.load(synthetic.rig(160, 120)).table_bundle()
+        if rank == 0:  # ONLY rank 0 ever sees the rig record
+            src = ca.Stereo.load(synthetic.rig(160, 120))
+            src.set_stereo_matching(object(), max_depth=3.5)
+            bundle = src.table_bundle()
         tabs = broadcast_tables(bundle, torch.device("cpu"), src=0)
-        ref = ca.Stereo.load(synthetic.rig(160, 120)).table_bundle()  # every rank can rebuild it to compare
-        ok = all(np.array_equal(tabs[k].numpy(), ref[k]) for k in ref)
-        # worker-rank side of the broadcast: the bundle becomes the rig's device tables without a rebuild
-        st = ca.Stereo.load(synthetic.rig(160, 120)).install_tables(tabs, torch.device("cpu"))
-        ok = ok and st._tables(torch.device("cpu"))["map2y"] is tabs["map2y"]
+        # worker-rank side of the broadcast: a rig from the bundle ALONE (6 maps + mask + 64 doubles)
+        st = ca.Stereo.from_bundle(tabs, torch.device("cpu"))
+        st.set_stereo_matching(object(), max_depth=3.5)
+        ok = st._tables(torch.device("cpu"))["map2y"] is tabs["map2y"]
+        ok = ok and st._unrectify_tables(torch.device("cpu"))[0] is tabs["unrect_mapx"]
+        ok = ok and sorted(tabs) == sorted(["map1x", "map1y", "map2x", "map2y", "mask", "unrect_mapx", "unrect_mapy", "params"])
+        nbytes = sum(t.numel() * t.element_size() for t in tabs.values())
+        ok = ok and nbytes == 160 * 120 * (6 * 4 + 1) + 64 * 8
+        # what the bundle-built rig derives must equal what a rig loaded from the record derives -- checked on every
+        # rank against a local rebuild that is used for NOTHING else
+        ref = ca.Stereo.load(synthetic.rig(160, 120))
+        ref.set_stereo_matching(object(), max_depth=3.5)
+        rb = ref.table_bundle()
+        ok = ok and all(np.array_equal(tabs[k].numpy(), rb[k]) for k in rb)
+        ok = ok and st.min_disparity == ref.min_disparity and st.baseline == ref.baseline and tuple(st.xy) == tuple(ref.xy)
+        ok = ok and all(np.array_equal(getattr(st, k), getattr(ref, k)) for k in ("K", "R1", "R2", "t"))
+        ok = ok and np.array_equal(st.cam1.K, ref.cam1.K) and np.array_equal(st.cam1.D, ref.cam1.D) \
+            and tuple(st.cam1.xy) == tuple(ref.cam1.xy) and tuple(st.cam2.xy) == tuple(ref.cam2.xy)
+        ok = ok and np.array_equal(st.rectify_valid_mask1, ref.rectify_valid_mask1)  # host views of the installed tables
+        ok = ok and np.array_equal(st.undistort_rectify_map2[1], ref.undistort_rectify_map2[1])
+        d = np.float32([[0.0, 3.5, 40.0], [7.25, 0.5, 12.0]])
+        ok = ok and np.array_equal(st.disparity_to_depth(d.copy()), ref.disparity_to_depth(d.copy()))
         lo, hi = shard_range(11, world, rank)
         thr = aggregate(hi - lo, 1.0 + rank, -5 - rank, torch.device("cpu"), distributed=True)
         total, tmax = thr["total_pairs"], thr["seconds"]
