@@ -12,13 +12,14 @@
 //                  the vertical box sum + P2.  Kept for blockSize 13 / 15 and as an A/B reference (CAMD_COST_SPLIT).
 //   k_band         (sgbm_band.hpp) fused aggregation: four directions per pass + WTA in the last
 //   k_scan         one aggregation direction as independent line scans from a zero border state;
-//                  a line is owned by a 2..16-lane group (8*NV disparities per lane, packed u16x2),
+//                  a line is owned by a 2..16-lane group (2*NR disparities per lane, packed u16x2),
 //                  neighbours d-1 / d+1 by DPP row shifts, min over d by a DPP butterfly
 //   k_wta          winner-take-all, uniqueness, sub-pixel parabola, right-view map via LDS
 //                  atomicMin on (cost << 16 | 0xFFFF - d), left-right check; one workgroup per row
 //   k_median3 / speckle (post.hip)
 //
-// All volumes are [pair][y][x][Dp] int16 with Dp = LANES*8*NV >= D; entries d >= D carry MAX_COST.
+// All volumes are [pair][y][x][Dp] int16 with Dp = LANES*2*NR >= D (NR packed u16x2 registers per lane); entries
+// d >= D carry MAX_COST.
 #include "common.hpp"
 
 #include <cstdlib>
@@ -38,7 +39,7 @@ struct Geom {
     int SW2;               // box radius
     int P1, P2, uniq, d12; // normalised parameters
     int ftzero;
-    int lanes, nv;         // line-group shape: Dp = lanes*8*nv
+    int lanes, nr;         // line-group shape: a lane holds nr packed registers = 2*nr disparities, Dp = lanes*2*nr
     int mode, npaths;
     uint32_t uniq_magic;   // floor(2^32 / (100 - uniq)) + 1, or 0 when 100 - uniq == 1 (band WTA)
     int speckleWindowSize, speckleRange;
@@ -320,22 +321,81 @@ __global__ __launch_bounds__(256) void k_vsum_reg(const uint4* __restrict__ Hs, 
 // k_scan: L_r along direction r = (dx, dy) for every line of the cost array, accumulated into S.
 //   L(p,d) = C(p,d) + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, minLp+P2) - (minLp+P2),  Lp = L(p-r,.)
 //   Lp = 0, minLp = 0 outside the array; Lp[-1] = Lp[D] = MAX_COST.
-// A line is owned by LANES lanes; lane l holds d in [l*8*NV, (l+1)*8*NV) as 4*NV packed u16 pairs.
+// A line is owned by LANES lanes; lane l holds d in [l*2*NR, (l+1)*2*NR) as NR packed u16 pairs.
 // All arithmetic is u16: real values are in [0, 32767], MAX_COST + P1 does not wrap, and the final
 // (C + m) - delta is exact modulo 2^16 (OpenCV's (CostType) cast).
 // ------------------------------------------------------------------------------------------------
 // directions of one launch: blockIdx.z selects the entry; with more than one entry every direction
 // writes its own volume (Sv + z * dir_stride, FIRST only) so that all of them run concurrently
+// ---- a lane's slice of a pixel's disparity vector: NR packed registers = 2*NR consecutive disparities = 4*NR bytes,
+// 4-byte aligned (16-byte aligned, and moved as uint4, when NR % 4 == 0).  In LDS a lane's slice takes NQ = ceil(NR/4)
+// 16-byte slots, the tail zero (lds_ld_regs / lds_st_regs below).
+template <int NR> struct __attribute__((packed, aligned(4))) RegVec { uint32_t v[NR]; };
+template <int NR>
+__device__ __forceinline__ void ld_regs(const uint16_t* __restrict__ p, uint32_t (&dst)[NR])
+{
+    if constexpr (NR % 4 == 0) {
+        const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+        for (int v = 0; v < NR / 4; v++) {
+            const uint4 w = q[v];
+            dst[4 * v] = w.x; dst[4 * v + 1] = w.y; dst[4 * v + 2] = w.z; dst[4 * v + 3] = w.w;
+        }
+    } else {
+        RegVec<NR> t;
+        __builtin_memcpy(&t, p, sizeof(t));
+#pragma unroll
+        for (int k = 0; k < NR; k++) dst[k] = t.v[k];
+    }
+}
+template <int NR>
+__device__ __forceinline__ void st_regs(uint16_t* __restrict__ p, const uint32_t (&src)[NR])
+{
+    if constexpr (NR % 4 == 0) {
+        uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+        for (int v = 0; v < NR / 4; v++) q[v] = make_uint4(src[4 * v], src[4 * v + 1], src[4 * v + 2], src[4 * v + 3]);
+    } else {
+        RegVec<NR> t;
+#pragma unroll
+        for (int k = 0; k < NR; k++) t.v[k] = src[k];
+        __builtin_memcpy(p, &t, sizeof(t));
+    }
+}
+template <int NR> __device__ __forceinline__ uint32_t reg_or0(const uint32_t (&a)[NR], int i) { return i < NR ? a[i < NR ? i : 0] : 0u; }
+// LDS: slot v of lane `idx` lives at p[v * stride + idx] -- one PLANE per slot, so that consecutive lanes are 16 bytes
+// apart in every ds_read_b128 / ds_write_b128 (lane-major slots, p[idx * NQ + v], put the lanes 32 bytes apart at
+// NQ = 2: two-way bank conflicts in every exchange of the D > 128 band passes, 44 % of their LDS cycles in round 4)
+template <int NR>
+__device__ __forceinline__ void lds_ld_regs(const uint4* p, int idx, int stride, uint32_t (&dst)[NR])
+{
+#pragma unroll
+    for (int v = 0; v < (NR + 3) / 4; v++) {
+        const uint4 w = p[v * stride + idx];
+        const uint32_t e[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (4 * v + k < NR) dst[4 * v + k] = e[k];
+    }
+}
+template <int NR>
+__device__ __forceinline__ void lds_st_regs(uint4* p, int idx, int stride, const uint32_t (&src)[NR])
+{
+#pragma unroll
+    for (int v = 0; v < (NR + 3) / 4; v++)
+        p[v * stride + idx] = make_uint4(reg_or0<NR>(src, 4 * v), reg_or0<NR>(src, 4 * v + 1), reg_or0<NR>(src, 4 * v + 2),
+                                         reg_or0<NR>(src, 4 * v + 3));
+}
+
 struct ScanDirs {
     int dx[8], dy[8], nlines[8];
     size_t dir_stride;
 };
 
-template <int LANES, int NV, bool FIRST, bool PAD>
+template <int LANES, int NR, bool FIRST, bool PAD>
 __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, uint16_t* __restrict__ Sbase,
                                               Geom g, ScanDirs sd, size_t vol_stride)
 {
-    constexpr int NR = 4 * NV;
     const int dx = sd.dx[blockIdx.z], dy = sd.dy[blockIdx.z], nlines = sd.nlines[blockIdx.z];
     uint16_t* __restrict__ Sv = Sbase + (size_t)blockIdx.z * sd.dir_stride;
     const int tid = blockIdx.x * 256 + threadIdx.x;
@@ -366,17 +426,16 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
         int ly = dy == 0 ? (1 << 30) : (dy > 0 ? H - y0 : y0 + 1);
         len = min(lx, ly);
     }
-    const size_t off = (size_t)pair * vol_stride + ((size_t)y0 * W1 + x0) * g.Dp + (size_t)li * (8 * NV);
+    const size_t off = (size_t)pair * vol_stride + ((size_t)y0 * W1 + x0) * g.Dp + (size_t)li * (2 * NR);
     const ptrdiff_t step = ((ptrdiff_t)dy * W1 + dx) * (ptrdiff_t)g.Dp;
-    const uint4* cp = reinterpret_cast<const uint4*>(Cv + off);
-    uint4* sp = reinterpret_cast<uint4*>(Sv + off);
-    const ptrdiff_t step4 = step / 8;
+    const uint16_t* cp = Cv + off;
+    uint16_t* sp = Sv + off;
 
     uint32_t keep[NR], sent[NR];
     if (PAD) {
 #pragma unroll
         for (int k = 0; k < NR; k++) {
-            int d0 = li * 8 * NV + 2 * k;
+            int d0 = li * 2 * NR + 2 * k;
             uint32_t kp = (d0 < g.D ? 0xffffu : 0u) | (d0 + 1 < g.D ? 0xffff0000u : 0u);
             keep[k] = kp;
             sent[k] = ~kp & SENT_PK;
@@ -390,33 +449,26 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
     uint32_t delta = P2pk;  // minLp = 0
     uint32_t edge_lo = SENT_PK, edge_hi = SENT_PK;
 
-    auto load = [&](const uint4* p, uint32_t* dst) {
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            uint4 q = p[v];
-            dst[4 * v] = q.x; dst[4 * v + 1] = q.y; dst[4 * v + 2] = q.z; dst[4 * v + 3] = q.w;
-        }
-    };
     // A line is a dependent chain (every pixel needs the previous one), so with one pair per call the kernel is
     // latency-bound: the C (and S) vectors of the next PF-1 pixels are kept in flight in a register ring.  The
     // loop is unrolled by PF so the ring never moves, and the loads are unconditional (clamped to the line's last
     // pixel) so that the compiler can wait with counted vmcnt(N) instead of draining the ring every step.
-    constexpr int PF = NV == 1 ? 8 : (NV == 2 ? 4 : 2);
+    constexpr int PF = NR <= 4 ? 8 : (NR <= 8 ? 4 : 2);
     uint32_t cr[PF][NR], sr[FIRST ? 1 : PF][NR];
 #pragma unroll
     for (int u = 0; u < PF - 1; u++) {
-        const ptrdiff_t o = (ptrdiff_t)min(u, len - 1) * step4;
-        load(cp + o, cr[u]);
-        if (!FIRST) load(sp + o, sr[u]);
+        const ptrdiff_t o = (ptrdiff_t)min(u, len - 1) * step;
+        ld_regs<NR>(cp + o, cr[u]);
+        if (!FIRST) ld_regs<NR>(sp + o, sr[u]);
     }
     for (int i0 = 0; i0 < len; i0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const int i = i0 + u;
             {
-                const ptrdiff_t o = (ptrdiff_t)min(i + PF - 1, len - 1) * step4;
-                load(cp + o, cr[(u + PF - 1) % PF]);
-                if (!FIRST) load(sp + o, sr[(u + PF - 1) % PF]);
+                const ptrdiff_t o = (ptrdiff_t)min(i + PF - 1, len - 1) * step;
+                ld_regs<NR>(cp + o, cr[(u + PF - 1) % PF]);
+                if (!FIRST) ld_regs<NR>(sp + o, sr[(u + PF - 1) % PF]);
             }
             if (i < len) {
                 const uint32_t(&c)[NR] = cr[u];
@@ -457,9 +509,7 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
                     s[k] = FIRST ? L[k] : pk_addsat_i16(sr[FIRST ? 0 : u][k], L[k]);
                     Lp[k] = L[k];
                 }
-                uint4* so = sp + (ptrdiff_t)i * step4;
-#pragma unroll
-                for (int v = 0; v < NV; v++) so[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
+                st_regs<NR>(sp + (ptrdiff_t)i * step, s);
             }
         }
     }
@@ -480,7 +530,7 @@ static constexpr uint32_t KEY_INIT = 0x7fff0000u;
 // (CostType)L (computeDisparitySGBM_HH4); 2: the same of saturate(L) (the 3-way loop) -- and every total is carried
 // as S + 32768 in an unsigned half, so that all comparisons below order the same way; `bias` turns them back into
 // values where the arithmetic needs them.
-template <int LANES, int NV, bool EXACT = false>
+template <int LANES, int NR, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, int16_t* __restrict__ disp,
                                              size_t disp_pitch_e, size_t disp_stride_e, Geom g,
                                              size_t vol_stride, int nvol, size_t dir_stride, int tie_lanes,
@@ -493,7 +543,6 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);          // [W]
     int16_t* d1row = reinterpret_cast<int16_t*>(keys + g.W);     // [W]
-    constexpr int NR = 4 * NV;
     constexpr int GROUPS = 256 / LANES;
     const int y = blockIdx.x, pair = blockIdx.y;
     const int li = threadIdx.x % LANES, grp = threadIdx.x / LANES;
@@ -505,30 +554,22 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
     }
     __syncthreads();
 
-    const uint16_t* Srow = Sv + (size_t)pair * vol_stride + ((size_t)y * g.W1) * g.Dp + (size_t)li * (8 * NV);
-    const int dbase = li * 8 * NV;
+    const uint16_t* Srow = Sv + (size_t)pair * vol_stride + ((size_t)y * g.W1) * g.Dp + (size_t)li * (2 * NR);
+    const int dbase = li * 2 * NR;
     for (int x = grp; x < g.W1; x += GROUPS) {
         uint32_t s[NR];
         if (!EXACT) {
-            const uint4* p = reinterpret_cast<const uint4*>(Srow + (size_t)x * g.Dp);
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                uint4 q = p[v];
-                s[4 * v] = q.x; s[4 * v + 1] = q.y; s[4 * v + 2] = q.z; s[4 * v + 3] = q.w;
-            }
+            ld_regs<NR>(Srow + (size_t)x * g.Dp, s);
             // concurrent-direction path: S = saturating sum of the per-direction volumes
             for (int dv = 1; dv < nvol; dv++) {
-                const uint4* pv = reinterpret_cast<const uint4*>(Srow + (size_t)dv * dir_stride + (size_t)x * g.Dp);
+                uint32_t q[NR];
+                ld_regs<NR>(Srow + (size_t)dv * dir_stride + (size_t)x * g.Dp, q);
 #pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    uint4 q = pv[v];
-                    s[4 * v] = pk_addsat_i16(s[4 * v], q.x); s[4 * v + 1] = pk_addsat_i16(s[4 * v + 1], q.y);
-                    s[4 * v + 2] = pk_addsat_i16(s[4 * v + 2], q.z); s[4 * v + 3] = pk_addsat_i16(s[4 * v + 3], q.w);
-                }
+                for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], q[k]);
             }
         } else {
             // (dir_stride and the row offsets count int elements here)
-            const int32_t* Lrow = reinterpret_cast<const int32_t*>(Sv) + ((size_t)y * g.W1 + x) * g.Dp + (size_t)li * (8 * NV);
+            const int32_t* Lrow = reinterpret_cast<const int32_t*>(Sv) + ((size_t)y * g.W1 + x) * g.Dp + (size_t)li * (2 * NR);
             int tot[2 * NR], part[2 * NR];
 #pragma unroll
             for (int e = 0; e < 2 * NR; e++) tot[e] = part[e] = 0;
@@ -544,15 +585,15 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
                     }
                 }
                 if (dv == nvol) break;
-                const int4* pv = reinterpret_cast<const int4*>(Lrow + (size_t)dv * dir_stride);
+                const int2* pv = reinterpret_cast<const int2*>(Lrow + (size_t)dv * dir_stride);  // 8-byte aligned: li * 2NR ints
 #pragma unroll
-                for (int v = 0; v < 2 * NV; v++) {
-                    const int4 q = pv[v];
-                    const int w[4] = {q.x, q.y, q.z, q.w};
+                for (int v = 0; v < NR; v++) {
+                    const int2 q = pv[v];
+                    const int w[2] = {q.x, q.y};
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < 2; k++) {
                         const int L = w[k];
-                        part[4 * v + k] += combine == 0 ? L : (combine == 1 ? (int)(int16_t)L
+                        part[2 * v + k] += combine == 0 ? L : (combine == 1 ? (int)(int16_t)L
                                                                              : (L < -32768 ? -32768 : (L > 32767 ? 32767 : L)));
                     }
                 }
@@ -572,7 +613,7 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
         }
         key = group_min_u32<LANES>(key);
         int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
-        if (tie_lanes == 8) {
+        if (NR % 4 == 0 && tie_lanes == 8) {  // (MODE_SGBM_3WAY keeps layouts of whole groups of 8 per lane: normalise())
             // MODE_SGBM_3WAY as OpenCV's CV_SIMD build decides ties (oracle/sgbm_ref.c way3_winner): the disparities
             // below E are scanned 8 at a time, every one of the 8 lane slots keeps the LAST d that attains its minimum,
             // the winner is the smallest of those positions among the slots that hold the global minimum; the scalar
@@ -594,7 +635,7 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
             for (int e = 0; e < 8; e++) {
                 uint32_t last = 0;  // 1 + the largest d of slot e (in this lane) whose total is the minimum
 #pragma unroll
-                for (int v = 0; v < NV; v++) {
+                for (int v = 0; v < NR / 4; v++) {
                     const int k = 4 * v + e / 2, d = dbase + 8 * v + e;
                     const uint32_t val = (e & 1) ? (s[k] >> 16) : (s[k] & 0xffffu);
                     if (d < E && val == m1) last = (uint32_t)d + 1;
@@ -816,11 +857,19 @@ static int normalise(const camd_sgbm_params* p, int width, int height, int cn, G
         return CAMD_ERR_UNSUPPORTED;
     }
     if (g->D > 512) { set_error("numDisparities %d > 512 not implemented", g->D); return CAMD_ERR_UNSUPPORTED; }
-    if (g->D > 64) { g->lanes = 16; g->nv = (g->D + 127) / 128; }
-    else if (g->D > 32) { g->lanes = 8; g->nv = 1; }
-    else if (g->D > 16) { g->lanes = 4; g->nv = 1; }
-    else { g->lanes = 2; g->nv = 1; }
-    g->Dp = g->lanes * 8 * g->nv;
+    // Layout of a pixel's disparity vector: `lanes` lanes x `nr` packed registers (2 disparities each).  With 16 lanes a
+    // register more per lane is 32 disparities, so numDisparities in (64, 256] is padded to the next multiple of 32 --
+    // the reference's 218 to 224, not to 256 (round 5; before, nr was a multiple of 4: 128 / 256 / 384 / 512) -- and every
+    // kernel moves and computes that much less.  MODE_SGBM_3WAY keeps whole groups of 8 disparities per lane (its
+    // 8-slot tie rule is evaluated per lane), as does everything beyond 256.
+    if (g->D > 64) {
+        g->lanes = 16;
+        g->nr = (g->D <= 256 && p->mode != CAMD_MODE_SGBM_3WAY) ? (g->D + 31) / 32 : 4 * ((g->D + 127) / 128);
+    }
+    else if (g->D > 32) { g->lanes = 8; g->nr = 4; }
+    else if (g->D > 16) { g->lanes = 4; g->nr = 4; }
+    else { g->lanes = 2; g->nr = 4; }
+    g->Dp = g->lanes * 2 * g->nr;
     return CAMD_OK;
 }
 
@@ -891,11 +940,45 @@ static int auto_concurrent_pairs(const Geom& g, bool band_ok, int max_batch, int
 // k_wta) covers uniquenessRatio <= 99.
 static bool band_supported(const Geom& g)
 {
-    const bool shape = g.W1 > 0 && ((g.lanes == 16 && g.nv <= 2) || (g.lanes <= 8 && g.nv == 1));
+    const bool shape = g.W1 > 0 && g.nr <= 8;  // (lanes < 16 always come with nr == 4)
     return shape && (g.mode == CAMD_MODE_SGBM_3WAY || g.uniq <= 99);
 }
 
 // ndirs directions in one launch (ndirs > 1 only with FIRST: each direction writes its own volume)
+// One kernel instantiation per line-group shape (lanes, nr): M(LANES, NR) for the handle's shape.  16 lanes take
+// nr = 3 .. 8 (numDisparities up to 256 in steps of 32), 12 and 16 (up to 384 / 512, scan kernels only).
+#define CAMD_FOR_SHAPE(g, M)                      \
+    do {                                          \
+        if ((g).lanes == 2) M(2, 4);              \
+        else if ((g).lanes == 4) M(4, 4);         \
+        else if ((g).lanes == 8) M(8, 4);         \
+        else switch ((g).nr) {                    \
+            case 3: M(16, 3); break;              \
+            case 4: M(16, 4); break;              \
+            case 5: M(16, 5); break;              \
+            case 6: M(16, 6); break;              \
+            case 7: M(16, 7); break;              \
+            case 8: M(16, 8); break;              \
+            case 12: M(16, 12); break;            \
+            default: M(16, 16);                   \
+        }                                         \
+    } while (0)
+// the same for the band passes (nr <= 8; band_supported)
+#define CAMD_FOR_BAND_SHAPE(g, M)                 \
+    do {                                          \
+        if ((g).lanes == 2) M(2, 4);              \
+        else if ((g).lanes == 4) M(4, 4);         \
+        else if ((g).lanes == 8) M(8, 4);         \
+        else switch ((g).nr) {                    \
+            case 3: M(16, 3); break;              \
+            case 4: M(16, 4); break;              \
+            case 5: M(16, 5); break;              \
+            case 6: M(16, 6); break;              \
+            case 7: M(16, 7); break;              \
+            default: M(16, 8);                    \
+        }                                         \
+    } while (0)
+
 template <bool FIRST>
 static int launch_scan(const camd_sgbm* h, const int (*dirs)[2], int ndirs, uint16_t* S, size_t dir_stride,
                        int batch, hipStream_t st)
@@ -920,13 +1003,7 @@ static int launch_scan(const camd_sgbm* h, const int (*dirs)[2], int ndirs, uint
         else hipLaunchKernelGGL((k_scan<LN, NVV, FIRST, false>), grid, dim3(256), 0, st, h->C, S, g, sd,    \
                                 h->vol_elems);                                                              \
     } while (0)
-    if (g.lanes == 2) CAMD_SCAN(2, 1);
-    else if (g.lanes == 4) CAMD_SCAN(4, 1);
-    else if (g.lanes == 8) CAMD_SCAN(8, 1);
-    else if (g.nv == 1) CAMD_SCAN(16, 1);
-    else if (g.nv == 2) CAMD_SCAN(16, 2);
-    else if (g.nv == 3) CAMD_SCAN(16, 3);
-    else CAMD_SCAN(16, 4);
+    CAMD_FOR_SHAPE(g, CAMD_SCAN);
 #undef CAMD_SCAN
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
@@ -943,13 +1020,7 @@ static int launch_wta(const camd_sgbm* h, const uint16_t* S, int nvol, size_t di
 #define CAMD_WTA(LN, NVV)                                                                       \
     hipLaunchKernelGGL((k_wta<LN, NVV>), grid, dim3(256), lds, st, S, disp, pitch_e, stride_e, g, \
                        h->vol_elems, nvol, dir_stride, tie_lanes)
-    if (g.lanes == 2) CAMD_WTA(2, 1);
-    else if (g.lanes == 4) CAMD_WTA(4, 1);
-    else if (g.lanes == 8) CAMD_WTA(8, 1);
-    else if (g.nv == 1) CAMD_WTA(16, 1);
-    else if (g.nv == 2) CAMD_WTA(16, 2);
-    else if (g.nv == 3) CAMD_WTA(16, 3);
-    else CAMD_WTA(16, 4);
+    CAMD_FOR_SHAPE(g, CAMD_WTA);
 #undef CAMD_WTA
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
@@ -971,40 +1042,46 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     // full passes: one workgroup per (pair, band); the row-parallel pass: the batch's rows in runs of R (sgbm_band.hpp)
     dim3 grid(full ? h->nbands * batch : div_up((long long)batch * g.H, BAND_THREADS / g.lanes)), block(BAND_BLOCK);
     const bool pad = g.Dp != g.D;
-#define CAMD_BAND(LN, NVV, FF, MM, DG)                                                                 \
-    do {                                                                                               \
-        if (pad) hipLaunchKernelGGL((k_band<LN, NVV, FF, MM, true, DG>), grid, block, 0, st, a, g);    \
-        else hipLaunchKernelGGL((k_band<LN, NVV, FF, MM, false, DG>), grid, block, 0, st, a, g);       \
-    } while (0)
-#define CAMD_BAND_SHAPE(FF, MM, DG)                                    \
-    do {                                                               \
-        if (g.lanes == 16 && g.nv == 1) CAMD_BAND(16, 1, FF, MM, DG);  \
-        else if (g.lanes == 16) CAMD_BAND(16, 2, FF, MM, DG);          \
-        else if (g.lanes == 8) CAMD_BAND(8, 1, FF, MM, DG);            \
-        else if (g.lanes == 4) CAMD_BAND(4, 1, FF, MM, DG);            \
-        else CAMD_BAND(2, 1, FF, MM, DG);                              \
-    } while (0)
-    if (full && mode == 0 && diag) CAMD_BAND_SHAPE(true, 0, true);
-    else if (full && mode == 2 && diag) CAMD_BAND_SHAPE(true, 2, true);
-    else if (full && mode == 0) CAMD_BAND_SHAPE(true, 0, false);
-    else if (full && mode == 2) CAMD_BAND_SHAPE(true, 2, false);
-    else if (!full && mode == 2 && tie8) {
-#define CAMD_BAND_TIE(LN, NVV)                                                                                  \
+    // (the shapes that exist since round 5, nr = 3 / 5 / 6 / 7, are instantiated in their padded form only: the
+    // unpadded one merely skips two masking operations per register, and D = Dp is the rare case there)
+#define CAMD_BAND(LN, NRR, FF, MM, DG)                                                                          \
     do {                                                                                                        \
-        if (pad) hipLaunchKernelGGL((k_band<LN, NVV, false, 2, true, true, true>), grid, block, 0, st, a, g);   \
-        else hipLaunchKernelGGL((k_band<LN, NVV, false, 2, false, true, true>), grid, block, 0, st, a, g);      \
+        if (pad || (NRR) % 4 != 0) hipLaunchKernelGGL((k_band<LN, NRR, FF, MM, true, DG>), grid, block, 0, st, a, g); \
+        else hipLaunchKernelGGL((k_band<LN, ((NRR) % 4 ? 4 : (NRR)), FF, MM, false, DG>), grid, block, 0, st, a, g);   \
     } while (0)
-        if (g.lanes == 16 && g.nv == 1) CAMD_BAND_TIE(16, 1);
-        else if (g.lanes == 16) CAMD_BAND_TIE(16, 2);
-        else if (g.lanes == 8) CAMD_BAND_TIE(8, 1);
-        else if (g.lanes == 4) CAMD_BAND_TIE(4, 1);
-        else CAMD_BAND_TIE(2, 1);
+#define CAMD_BAND_F0T(LN, NRR) CAMD_BAND(LN, NRR, true, 0, true)
+#define CAMD_BAND_F2T(LN, NRR) CAMD_BAND(LN, NRR, true, 2, true)
+#define CAMD_BAND_F0F(LN, NRR) CAMD_BAND(LN, NRR, true, 0, false)
+#define CAMD_BAND_F2F(LN, NRR) CAMD_BAND(LN, NRR, true, 2, false)
+#define CAMD_BAND_R2(LN, NRR) CAMD_BAND(LN, NRR, false, 2, true)
+#define CAMD_BAND_R1(LN, NRR) CAMD_BAND(LN, NRR, false, 1, true)
+    if (full && mode == 0 && diag) CAMD_FOR_BAND_SHAPE(g, CAMD_BAND_F0T);
+    else if (full && mode == 2 && diag) CAMD_FOR_BAND_SHAPE(g, CAMD_BAND_F2T);
+    else if (full && mode == 0) CAMD_FOR_BAND_SHAPE(g, CAMD_BAND_F0F);
+    else if (full && mode == 2) CAMD_FOR_BAND_SHAPE(g, CAMD_BAND_F2F);
+    else if (!full && mode == 2 && tie8) {
+        // MODE_SGBM_3WAY: nr is a multiple of 4 (normalise)
+#define CAMD_BAND_TIE(LN, NRR)                                                                                  \
+    do {                                                                                                        \
+        if (pad) hipLaunchKernelGGL((k_band<LN, NRR, false, 2, true, true, true>), grid, block, 0, st, a, g);   \
+        else hipLaunchKernelGGL((k_band<LN, NRR, false, 2, false, true, true>), grid, block, 0, st, a, g);      \
+    } while (0)
+        if (g.lanes == 16 && g.nr == 4) CAMD_BAND_TIE(16, 4);
+        else if (g.lanes == 16) CAMD_BAND_TIE(16, 8);
+        else if (g.lanes == 8) CAMD_BAND_TIE(8, 4);
+        else if (g.lanes == 4) CAMD_BAND_TIE(4, 4);
+        else CAMD_BAND_TIE(2, 4);
 #undef CAMD_BAND_TIE
     }
-    else if (!full && mode == 2) CAMD_BAND_SHAPE(false, 2, true);
-    else if (!full && mode == 1) CAMD_BAND_SHAPE(false, 1, true);
+    else if (!full && mode == 2) CAMD_FOR_BAND_SHAPE(g, CAMD_BAND_R2);
+    else if (!full && mode == 1) CAMD_FOR_BAND_SHAPE(g, CAMD_BAND_R1);
     else { set_error("band pass (full %d, mode %d) not instantiated", (int)full, mode); return CAMD_ERR_UNSUPPORTED; }
-#undef CAMD_BAND_SHAPE
+#undef CAMD_BAND_F0T
+#undef CAMD_BAND_F2T
+#undef CAMD_BAND_F0F
+#undef CAMD_BAND_F2F
+#undef CAMD_BAND_R2
+#undef CAMD_BAND_R1
 #undef CAMD_BAND
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
@@ -1054,13 +1131,7 @@ static int launch_exact(const camd_sgbm* h, int vp, int16_t* dst, hipStream_t st
         else hipLaunchKernelGGL((k_scan_exact<LN, NVV, false>), grid, dim3(256), 0, st, C, L, g, sd, h->cost_neg, vp,         \
                                 g.mode == CAMD_MODE_HH4 ? 1 : 0);                                                             \
     } while (0)
-    if (g.lanes == 2) CAMD_XSCAN(2, 1);
-    else if (g.lanes == 4) CAMD_XSCAN(4, 1);
-    else if (g.lanes == 8) CAMD_XSCAN(8, 1);
-    else if (g.nv == 1) CAMD_XSCAN(16, 1);
-    else if (g.nv == 2) CAMD_XSCAN(16, 2);
-    else if (g.nv == 3) CAMD_XSCAN(16, 3);
-    else CAMD_XSCAN(16, 4);
+    CAMD_FOR_SHAPE(g, CAMD_XSCAN);
 #undef CAMD_XSCAN
     CAMD_LAUNCH_CHECK();
     const int tie_lanes = way3 ? h->way3_simd_lanes : 0;
@@ -1069,13 +1140,7 @@ static int launch_exact(const camd_sgbm* h, int vp, int16_t* dst, hipStream_t st
 #define CAMD_XWTA(LN, NVV)                                                                                          \
     hipLaunchKernelGGL((k_wta<LN, NVV, true>), dim3(g.H, 1), dim3(256), lds, st, reinterpret_cast<const uint16_t*>(L), \
                        dst, (size_t)g.W, (size_t)0, g, (size_t)0, nd, sd.dir_stride, tie_lanes, combine, h->cost_neg, vp)
-    if (g.lanes == 2) CAMD_XWTA(2, 1);
-    else if (g.lanes == 4) CAMD_XWTA(4, 1);
-    else if (g.lanes == 8) CAMD_XWTA(8, 1);
-    else if (g.nv == 1) CAMD_XWTA(16, 1);
-    else if (g.nv == 2) CAMD_XWTA(16, 2);
-    else if (g.nv == 3) CAMD_XWTA(16, 3);
-    else CAMD_XWTA(16, 4);
+    CAMD_FOR_SHAPE(g, CAMD_XWTA);
 #undef CAMD_XWTA
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
@@ -1107,7 +1172,7 @@ size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int heigh
     if (band_ok) {
         const int R = BAND_THREADS / g.lanes;
         size_t nb = (size_t)div_up(vrows, R);
-        total += (size_t)max_batch * cr.n * nb * (band_erec_stride(g.W1, g.lanes, g.nv) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
+        total += (size_t)max_batch * cr.n * nb * (band_erec_stride(g.W1, g.lanes, (g.nr + 3) / 4) * 8 + (size_t)div_up(g.W1, BAND_CHUNK) * 4);
         total += (size_t)max_batch * cr.n * vrows * width * 6;
     }
     // per-direction volumes: the latency path's, and one set of int volumes for the exact aggregation where the
@@ -1189,7 +1254,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
         const int R = BAND_THREADS / g.lanes;
         h->nbands = div_up(vrows, R);  // bands of one (virtual) pair
         h->nchunks = div_up(g.W1, BAND_CHUNK);
-        h->erec_stride = band_erec_stride(g.W1, g.lanes, g.nv);
+        h->erec_stride = band_erec_stride(g.W1, g.lanes, (g.nr + 3) / 4);
         size_t nflags = nvol * h->nbands * h->nchunks;
         size_t npix = nvol * vrows * width;  // the winner-take-all state of every (virtual) pair
         if (e == hipSuccess) e = hipMalloc((void**)&h->E, nvol * h->nbands * h->erec_stride * 8);

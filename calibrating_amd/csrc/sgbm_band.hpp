@@ -58,7 +58,7 @@ static constexpr uint32_t BAND_SPIN_LIMIT = 1u << 20;    // ~0.1 s of s_sleep po
 struct BandArgs {
     const uint16_t* C;
     uint16_t* S;
-    unsigned long long* E;  // [pair][band] edge blocks: [W1][6*NV][LANES] u64 vector words, then [W1][2] u64 deltas
+    unsigned long long* E;  // [pair][band] edge blocks: [W1][6*NQ][LANES] u64 vector words, then [W1][2] u64 deltas
     uint32_t* flags;        // [pair][band][nchunks], value == epoch when the chunk is published
     uint32_t* ticket;       // zeroed before every launch
     uint32_t* err;          // set to 1 if a bounded spin timed out
@@ -111,8 +111,8 @@ __device__ __forceinline__ uint32_t sgm_step(const uint32_t (&Lp)[NR], uint32_t 
 }
 
 
-// u64 words of one (pair, band) edge block: per column LANES x 6NV vector words, then 2 words of deltas
-static inline size_t band_erec_stride(int W1, int lanes, int nv) { return (size_t)W1 * ((size_t)lanes * 6 * nv + 2); }
+// u64 words of one (pair, band) edge block: per column LANES x 6NQ vector words, then 2 words of deltas
+static inline size_t band_erec_stride(int W1, int lanes, int nq) { return (size_t)W1 * ((size_t)lanes * 6 * nq + 2); }  // nq = ceil(nr / 4)
 
 // Winner-take-all on the final S of one pixel (bit-exact with k_wta), in two parts.
 //   band_wta_step   every step, all lanes of the group: minS / best by a min-reduce over keys, the uniqueness
@@ -122,26 +122,28 @@ static inline size_t band_erec_stride(int W1, int lanes, int nv) { return (size_
 // dpk[k] = the two disparities of register k, packed (d | d+1 << 16).
 static constexpr uint32_t WTA_NONE = 0xffffffffu;
 // The parked S vectors of the groups of a wave are read back at [best - 1] / [best + 1] with 2-byte reads (32-bank
-// modulus, two groups per 32-lane half).  At a group stride of LANES * 16 * NV bytes = a multiple of 128 the groups of a
+// modulus, two groups per 32-lane half).  At a group stride of LANES * 16 bytes = a multiple of 128 the groups of a
 // half hit the same bank whenever their winners share a dword -- neighbouring rows of a real scene nearly always do
 // (round 4: SQ_LDS_BANK_CONFLICT = 24 % of the LDS-active cycles of the row-parallel pass).  CAMD_WTA_PADQ uint4 of padding
 // per group (WtaPad) move the second group of a half by 16 banks: a conflict then needs winners 32 disparities apart.
 #ifndef CAMD_WTA_PADQ
 #define CAMD_WTA_PADQ 4
 #endif
-// (only where the group stride is a multiple of 128 bytes: 8 or 16 lanes per pixel)
-template <int LANES, int NV> struct WtaPad { static constexpr int Q = (LANES * NV * 16) % 128 == 0 ? CAMD_WTA_PADQ : 0; };
+// (only where the group stride is a multiple of 128 bytes: 8 or 16 lanes per pixel; the slots of a lane are planes of
+// their own -- lds_st_regs -- so the group stride does not depend on the registers per lane)
+template <int LANES> struct WtaPad { static constexpr int Q = (LANES * 16) % 128 == 0 ? CAMD_WTA_PADQ : 0; };
 
 // TIE8: MODE_SGBM_3WAY's winner among equal totals as OpenCV's CV_SIMD build picks it (k_wta, oracle way3_winner),
 // for D % 8 == 0: disparities are scanned 8 at a time, each of the 8 lane slots keeps the LAST d attaining the
 // minimum, the winner is the smallest of those positions.  With a single minimum that is the ordinary winner, so the
 // rule is only evaluated when some pixel of the wave has its first and last minimum at different d.
-template <int LANES, int NV, bool TIE8 = false>
-__device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const uint32_t (&dpk)[4 * NV], uint4* wS,
+template <int LANES, int NR, bool TIE8 = false>
+__device__ __forceinline__ void band_wta_step(const uint32_t (&s)[NR], const uint32_t (&dpk)[NR], uint4* wS,
                                               const Geom& g, int ctid, int grp, int li, int t, bool act,
                                               uint32_t& cap_key, uint32_t& cap_nb)
 {
-    constexpr int NR = 4 * NV;
+    constexpr int NQ = (NR + 3) / 4;
+    static_assert(!TIE8 || NR % 4 == 0, "the 8-slot tie rule needs whole groups of 8 disparities per lane");
     // (1) minS and the smallest d attaining it: min over keys (S << 16 | d); padded d >= D hold 0x7FFF
     uint32_t key = 0xffffffffu;
 #pragma unroll
@@ -167,7 +169,7 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const
             for (int e = 0; e < 8; e++) {
                 uint32_t last = 0;  // 1 + the largest d of slot e (in this lane) whose total is the minimum
 #pragma unroll
-                for (int v = 0; v < NV; v++) {
+                for (int v = 0; v < NR / 4; v++) {
                     const uint32_t val = (e & 1) ? (s[4 * v + e / 2] >> 16) : (s[4 * v + e / 2] & 0xffffu);
                     const uint32_t d = (e & 1) ? (dpk[4 * v + e / 2] >> 16) : (dpk[4 * v + e / 2] & 0xffffu);
                     if ((int)d < g.D && (int)val == minS) last = d + 1;
@@ -180,9 +182,9 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const
         }
     }
     // park S so that S[best-1], S[best+1] can be picked without a select tree
-#pragma unroll
-    for (int v = 0; v < NV; v++)
-        wS[grp * (LANES * NV + WtaPad<LANES, NV>::Q) + li * NV + v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
+    // plane v of the parked vectors: [group][LANES + pad] uint4 (see WtaPad); WS_PLANE uint4 per plane
+    constexpr int GST = LANES + WtaPad<LANES>::Q, WS_PLANE = (BAND_THREADS / LANES) * GST;
+    lds_st_regs<NR>(wS, grp * GST + li, WS_PLANE, s);
     // (2) uniqueness: S[d]*(100-u) < minS*100 for some |d-best| > 1
     //     <=>  min over those d of S[d]  <=  T = floor((minS*100 - 1) / (100-u)); the division by the launch
     //     constant 100-u is a multiply-high by floor(2^32/(100-u)) + 1, exact for numerators < 2^32/100
@@ -203,8 +205,14 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const
     const int minfar = (int)(group_min_dup16<LANES>(far) & 0xffffu);
     const bool ok = act && minS < MAX_COST && minfar > T;
     // (3) neighbours for the sub-pixel parabola (same address in every lane of the group: an LDS broadcast)
-    const uint16_t* gs = reinterpret_cast<const uint16_t*>(wS + grp * (LANES * NV + WtaPad<LANES, NV>::Q));
-    const uint32_t Sm = gs[max(best - 1, 0)], Sp = gs[min(best + 1, LANES * 8 * NV - 1)];
+    const uint16_t* gs = reinterpret_cast<const uint16_t*>(wS + grp * GST);
+    // disparity d sits in lane d / (2 NR), element w = d % (2 NR): plane w / 8, u16 (lane * 8 + w % 8) of the group's row
+    auto slot_of = [](int d) {
+        if (NQ == 1 && NR == 4) return d;
+        const int ln = d / (2 * NR), w = d - ln * (2 * NR);
+        return (w >> 3) * (WS_PLANE * 8) + ln * 8 + (w & 7);
+    };
+    const uint32_t Sm = gs[slot_of(max(best - 1, 0))], Sp = gs[slot_of(min(best + 1, LANES * 2 * NR - 1))];
     if (li == (t & (LANES - 1))) {
         cap_key = ok ? key : WTA_NONE;
         cap_nb = Sm | (Sp << 16);
@@ -212,7 +220,7 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[4 * NV], const
 }
 
 // x: column (cost coordinates) of the pixel this lane captured
-template <int LANES, int NV>
+template <int LANES>
 __device__ __forceinline__ void band_wta_flush(const BandArgs& a, const Geom& g, int pair, int y, int x,
                                                uint32_t& cap_key, uint32_t cap_nb)
 {
@@ -247,16 +255,16 @@ __device__ __forceinline__ void band_wta_flush(const BandArgs& a, const Geom& g,
 // FULL: H, V, Dg, A of sweep (sx, sy), skew 2.  !FULL: H of sweep sx only (rows independent).
 // MODE: 0 = first pass (S written), 2 = final (S read, WTA; S stored only for the parity hook)
 // DIAG = false (MODE_HH4): the two diagonal directions are left out (their slots travel as zeros)
-template <int LANES, int NV, bool FULL, int MODE, bool PAD, bool DIAG = true, bool TIE8 = false>
-__global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void k_band(BandArgs a, Geom g)
+template <int LANES, int NR, bool FULL, int MODE, bool PAD, bool DIAG = true, bool TIE8 = false>
+__global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? CAMD_BAND_MIN_WAVES : 2) void k_band(BandArgs a, Geom g)
 {
-    constexpr int NR = 4 * NV;
+    constexpr int NQ = (NR + 3) / 4;  // 16-byte LDS slots / u64 edge-record pairs per lane and vector
     constexpr int R = BAND_THREADS / LANES;
-    constexpr int EVEC = 6 * NV;     // u64 per lane per column: V (2NV), Dg (2NV), A (2NV)
+    constexpr int EVEC = 6 * NQ;     // u64 per lane per column: V (2NQ), Dg (2NQ), A (2NQ)
     constexpr int CPB = 64 / LANES;  // columns the helper wave fetches per batch
     constexpr int RING = FULL ? BAND_RING : BAND_RING_ROWS;
     constexpr int SK = FULL ? 2 : 0;
-    constexpr int XN = FULL ? BAND_THREADS * NV : 1, EN = FULL ? 64 * NV : 1;
+    constexpr int XN = FULL ? BAND_THREADS * NQ : 1, EN = FULL ? 64 * NQ : 1;
 
     __shared__ uint4 xV[2][XN];
     __shared__ uint4 xD[2][XN];
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void
     __shared__ uint4 eD[3][EN];
     __shared__ uint4 eA[3][EN];
     __shared__ uint4 edl[3][FULL ? CPB : 1];
-    __shared__ uint4 wS[MODE == 2 ? BAND_THREADS * NV + R * WtaPad<LANES, NV>::Q : 1];  // FINAL: S of the current pixel, per group
+    __shared__ uint4 wS[MODE == 2 ? NQ * R * (LANES + WtaPad<LANES>::Q) : 1];  // FINAL: S of the current pixel, per group
     __shared__ uint32_t s_ticket;
 
     if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1u);
@@ -302,32 +310,19 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void
     uint32_t keep[NR], sent[NR], dpk[NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-        int d0 = li * 8 * NV + 2 * k;
+        int d0 = li * 2 * NR + 2 * k;
         dpk[k] = (uint32_t)d0 | ((uint32_t)(d0 + 1) << 16);
         uint32_t kp = (d0 < g.D ? 0xffffu : 0u) | (d0 + 1 < g.D ? 0xffff0000u : 0u);
         keep[k] = kp;
         sent[k] = ~kp & SENT_PK;
     }
 
-    const size_t rowoff = (size_t)pair * a.vol_stride + ((size_t)(rvalid ? y : 0) * W1) * g.Dp + (size_t)li * (8 * NV);
+    const size_t rowoff = (size_t)pair * a.vol_stride + ((size_t)(rvalid ? y : 0) * W1) * g.Dp + (size_t)li * (2 * NR);
     const uint16_t* Crow = a.C + rowoff;
     uint16_t* Srow = a.S + rowoff;
     auto cell_off = [&](int xi) -> size_t { return (size_t)(a.sx > 0 ? xi : W1 - 1 - xi) * g.Dp; };
-    auto load_vec = [&](const uint16_t* p, uint32_t (&dst)[NR]) {
-        const uint4* q = reinterpret_cast<const uint4*>(p);
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            uint4 w = q[v];
-            dst[4 * v] = w.x; dst[4 * v + 1] = w.y; dst[4 * v + 2] = w.z; dst[4 * v + 3] = w.w;
-        }
-    };
-    auto lds_vec = [&](const uint4* p, uint32_t (&dst)[NR]) {
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            uint4 w = p[v];
-            dst[4 * v] = w.x; dst[4 * v + 1] = w.y; dst[4 * v + 2] = w.z; dst[4 * v + 3] = w.w;
-        }
-    };
+    auto load_vec = [&](const uint16_t* p, uint32_t (&dst)[NR]) { ld_regs<NR>(p, dst); };
+    auto lds_vec = [&](const uint4* p, int idx, int stride, uint32_t (&dst)[NR]) { lds_ld_regs<NR>(p, idx, stride, dst); };
 
     // ---- edge buffers ------------------------------------------------------------------------------
     unsigned long long* Eout = a.E + ((size_t)pair * a.nbands + band) * a.erec_stride;
@@ -375,15 +370,15 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void
     auto park_batch = [&](int b) {
         const int slot = b % 3;
 #pragma unroll
-        for (int v = 0; v < NV; v++) {
-            eV[slot][hl * NV + v] = make_uint4((uint32_t)pend[2 * v], (uint32_t)(pend[2 * v] >> 32),
+        for (int v = 0; v < NQ; v++) {
+            eV[slot][v * 64 + hl] = make_uint4((uint32_t)pend[2 * v], (uint32_t)(pend[2 * v] >> 32),
                                                (uint32_t)pend[2 * v + 1], (uint32_t)(pend[2 * v + 1] >> 32));
-            eD[slot][hl * NV + v] =
-                make_uint4((uint32_t)pend[2 * NV + 2 * v], (uint32_t)(pend[2 * NV + 2 * v] >> 32),
-                           (uint32_t)pend[2 * NV + 2 * v + 1], (uint32_t)(pend[2 * NV + 2 * v + 1] >> 32));
-            eA[slot][hl * NV + v] =
-                make_uint4((uint32_t)pend[4 * NV + 2 * v], (uint32_t)(pend[4 * NV + 2 * v] >> 32),
-                           (uint32_t)pend[4 * NV + 2 * v + 1], (uint32_t)(pend[4 * NV + 2 * v + 1] >> 32));
+            eD[slot][v * 64 + hl] =
+                make_uint4((uint32_t)pend[2 * NQ + 2 * v], (uint32_t)(pend[2 * NQ + 2 * v] >> 32),
+                           (uint32_t)pend[2 * NQ + 2 * v + 1], (uint32_t)(pend[2 * NQ + 2 * v + 1] >> 32));
+            eA[slot][v * 64 + hl] =
+                make_uint4((uint32_t)pend[4 * NQ + 2 * v], (uint32_t)(pend[4 * NQ + 2 * v] >> 32),
+                           (uint32_t)pend[4 * NQ + 2 * v + 1], (uint32_t)(pend[4 * NQ + 2 * v + 1] >> 32));
         }
         if (hl % LANES == 0)
             edl[slot][hl / LANES] = make_uint4((uint32_t)pdl[0], (uint32_t)(pdl[0] >> 32), (uint32_t)pdl[1], 0u);
@@ -429,18 +424,18 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void
         if (!helper) {
             // slot 1 is what step 0 reads as "produced in step -1": the zero border state
 #pragma unroll
-            for (int v = 0; v < NV; v++) {
-                xV[1][ctid * NV + v] = make_uint4(0u, 0u, 0u, 0u);
-                xD[1][ctid * NV + v] = make_uint4(0u, 0u, 0u, 0u);
-                xA[1][ctid * NV + v] = make_uint4(0u, 0u, 0u, 0u);
+            for (int v = 0; v < NQ; v++) {
+                xV[1][v * BAND_THREADS + ctid] = make_uint4(0u, 0u, 0u, 0u);
+                xD[1][v * BAND_THREADS + ctid] = make_uint4(0u, 0u, 0u, 0u);
+                xA[1][v * BAND_THREADS + ctid] = make_uint4(0u, 0u, 0u, 0u);
             }
             if (li == 0) xdl[1][grp] = make_uint4(P2pk, P2pk, P2pk, 0u);
         }
         __syncthreads();  // edge batch 0 is parked
         if (!helper && grp == 0 && has_prev) {
             // column 0 of the band above: V input of step 0 (set 1), Dg input of step 1 (set 3)
-            lds_vec(&eV[0][li * NV], VS[1]);
-            lds_vec(&eD[0][li * NV], DS[3]);
+            lds_vec(eV[0], li, 64, VS[1]);
+            lds_vec(eD[0], li, 64, DS[3]);
             const uint4 dl = edl[0][0];
             dVs[1] = dl.x;
             dDs[3] = dl.y;
@@ -488,19 +483,19 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void
             if (FULL) {
                 const int rb = (u & 1) ^ 1;
                 if (grp > 0) {
-                    lds_vec(&xV[rb][(ctid - LANES) * NV], VS[u & 1]);
-                    lds_vec(&xD[rb][(ctid - LANES) * NV], DS[u & 3]);
-                    lds_vec(&xA[rb][(ctid - LANES) * NV], An);
+                    lds_vec(xV[rb], ctid - LANES, BAND_THREADS, VS[u & 1]);
+                    lds_vec(xD[rb], ctid - LANES, BAND_THREADS, DS[u & 3]);
+                    lds_vec(xA[rb], ctid - LANES, BAND_THREADS, An);
                     const uint4 dl = xdl[rb][grp - 1];
                     dVs[u & 1] = dl.x;
                     dDs[u & 3] = dl.y;
                     dAn = dl.z;
                 } else if (has_prev && xi + 1 < W1) {
                     const int col = xi + 1;
-                    const int slot = (col / CPB) % 3, e = ((col % CPB) * LANES + li) * NV;
-                    lds_vec(&eV[slot][e], VS[u & 1]);
-                    lds_vec(&eD[slot][e], DS[u & 3]);
-                    lds_vec(&eA[slot][e], An);
+                    const int slot = (col / CPB) % 3, e = (col % CPB) * LANES + li;
+                    lds_vec(eV[slot], e, 64, VS[u & 1]);
+                    lds_vec(eD[slot], e, 64, DS[u & 3]);
+                    lds_vec(eA[slot], e, 64, An);
                     const uint4 dl = edl[slot][col % CPB];
                     dVs[u & 1] = dl.x;
                     dDs[u & 3] = dl.y;
@@ -538,37 +533,33 @@ __global__ __launch_bounds__(BAND_BLOCK, NV == 1 ? CAMD_BAND_MIN_WAVES : 2) void
                     }
                 }
                 if (MODE != 2 || a.write_S) {
-                    uint4* sp = reinterpret_cast<uint4*>(Srow + cell_off(xi));
-#pragma unroll
-                    for (int v = 0; v < NV; v++) sp[v] = make_uint4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
+                    st_regs<NR>(Srow + cell_off(xi), s);
                 }
-                if (MODE == 2) band_wta_step<LANES, NV, TIE8>(s, dpk, wS, g, ctid, grp, li, t, true, cap_key, cap_nb);
+                if (MODE == 2) band_wta_step<LANES, NR, TIE8>(s, dpk, wS, g, ctid, grp, li, t, true, cap_key, cap_nb);
             }
             if (MODE == 2 && ((t & (LANES - 1)) == LANES - 1 || t == nsteps - 1)) {
                 // lane li captured the pixel of step t - ((t mod LANES) - li)
                 const int xc = xi - ((t & (LANES - 1)) - li);
-                band_wta_flush<LANES, NV>(a, g, pair, y, a.sx > 0 ? xc : W1 - 1 - xc, cap_key, cap_nb);
+                band_wta_flush<LANES>(a, g, pair, y, a.sx > 0 ? xc : W1 - 1 - xc, cap_key, cap_nb);
             }
             if (FULL) {
                 const int wb = u & 1;
-#pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    xV[wb][ctid * NV + v] = make_uint4(LVo[4 * v], LVo[4 * v + 1], LVo[4 * v + 2], LVo[4 * v + 3]);
-                    xD[wb][ctid * NV + v] = make_uint4(LDo[4 * v], LDo[4 * v + 1], LDo[4 * v + 2], LDo[4 * v + 3]);
-                    xA[wb][ctid * NV + v] = make_uint4(LAo[4 * v], LAo[4 * v + 1], LAo[4 * v + 2], LAo[4 * v + 3]);
-                }
+                lds_st_regs<NR>(xV[wb], ctid, BAND_THREADS, LVo);
+                lds_st_regs<NR>(xD[wb], ctid, BAND_THREADS, LDo);
+                lds_st_regs<NR>(xA[wb], ctid, BAND_THREADS, LAo);
                 if (li == 0) xdl[wb][grp] = make_uint4(dVo, dDo, dAo, 0u);
                 if (producer && act) {
                     unsigned long long* p = Eout + (size_t)xi * (LANES * EVEC) + li;
 #pragma unroll
-                    for (int k = 0; k < 2 * NV; k++) {
-                        __hip_atomic_store(p + k * LANES, (unsigned long long)LVo[2 * k] | ((unsigned long long)LVo[2 * k + 1] << 32),
+                    for (int k = 0; k < 2 * NQ; k++) {
+                        if (2 * k >= NR) break;  // (slots past the lane's registers are never read back as anything but padding)
+                        __hip_atomic_store(p + k * LANES, (unsigned long long)LVo[2 * k] | ((unsigned long long)reg_or0<NR>(LVo, 2 * k + 1) << 32),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(p + (2 * NV + k) * LANES,
-                                           (unsigned long long)LDo[2 * k] | ((unsigned long long)LDo[2 * k + 1] << 32),
+                        __hip_atomic_store(p + (2 * NQ + k) * LANES,
+                                           (unsigned long long)LDo[2 * k] | ((unsigned long long)reg_or0<NR>(LDo, 2 * k + 1) << 32),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(p + (4 * NV + k) * LANES,
-                                           (unsigned long long)LAo[2 * k] | ((unsigned long long)LAo[2 * k + 1] << 32),
+                        __hip_atomic_store(p + (4 * NQ + k) * LANES,
+                                           (unsigned long long)LAo[2 * k] | ((unsigned long long)reg_or0<NR>(LAo, 2 * k + 1) << 32),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (li == 0) {

@@ -67,12 +67,12 @@ __device__ __forceinline__ int sat16i(int v) { return v < -32768 ? -32768 : (v >
 // STORE_SAT: how L is narrowed to int16 for the recursion itself -- false: the (CostType) cast of
 // computeDisparitySGBM / computeDisparitySGBM_HH4 (wraps), true: the saturate_cast of the 3-way loop
 // (oracle/sgbm_ref.c:768-774), whose minimum is taken over the narrowed values.
-template <int LANES, int NV, bool STORE_SAT>
+template <int LANES, int NR, bool STORE_SAT>
 __global__ __launch_bounds__(256) void k_scan_exact(const int16_t* __restrict__ Cv, int32_t* __restrict__ Lout, Geom g,
                                                     ScanDirs sd, const uint32_t* __restrict__ neg, int vp, int min_as_int)
 {
     if (!neg[vp]) return;
-    constexpr int NE = 8 * NV;  // disparities per lane
+    constexpr int NE = 2 * NR;  // disparities per lane
     const int dx = sd.dx[blockIdx.z], dy = sd.dy[blockIdx.z], nlines = sd.nlines[blockIdx.z];
     int32_t* __restrict__ Lv = Lout + (size_t)blockIdx.z * sd.dir_stride;
     const int tid = blockIdx.x * 256 + threadIdx.x;
@@ -108,15 +108,12 @@ __global__ __launch_bounds__(256) void k_scan_exact(const int16_t* __restrict__ 
     for (int j = 0; j < NE; j++) Lp[j] = 0;
     int minLp = 0;
     auto load8 = [&](const int16_t* p, int (&dst)[NE]) {
+        uint32_t w[NR];
+        ld_regs<NR>(reinterpret_cast<const uint16_t*>(p), w);
 #pragma unroll
-        for (int v = 0; v < NV; v++) {
-            const uint4 q = reinterpret_cast<const uint4*>(p)[v];
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                dst[8 * v + 2 * k] = (int)(int16_t)(w[k] & 0xffffu);
-                dst[8 * v + 2 * k + 1] = (int)(int16_t)(w[k] >> 16);
-            }
+        for (int k = 0; k < NR; k++) {
+            dst[2 * k] = (int)(int16_t)(w[k] & 0xffffu);
+            dst[2 * k + 1] = (int)(int16_t)(w[k] >> 16);
         }
     };
     int c[NE], cn[NE];
@@ -145,9 +142,9 @@ __global__ __launch_bounds__(256) void k_scan_exact(const int16_t* __restrict__ 
         // computeDisparitySGBM stores the minimum as CostType; computeDisparitySGBM_HH4 hands it on as the int it is
         // (oracle/sgbm_ref.c:370-374 against :478-488, :545)
         minLp = (STORE_SAT || min_as_int) ? mn : (int)(int16_t)mn;
-        int4* o = reinterpret_cast<int4*>(lp_out + (ptrdiff_t)i * step);
+        int2* o = reinterpret_cast<int2*>(lp_out + (ptrdiff_t)i * step);  // 8-byte aligned: li * 2NR ints
 #pragma unroll
-        for (int v = 0; v < 2 * NV; v++) o[v] = make_int4(Lint[4 * v], Lint[4 * v + 1], Lint[4 * v + 2], Lint[4 * v + 3]);
+        for (int v = 0; v < NR; v++) o[v] = make_int2(Lint[2 * v], Lint[2 * v + 1]);
 #pragma unroll
         for (int j = 0; j < NE; j++) { Lp[j] = L[j]; c[j] = cn[j]; }
     }
