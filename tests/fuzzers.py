@@ -35,7 +35,7 @@ def fuzz_sgbm(n, seed=77, log=print):
     br, bad = {}, []
     for case in range(n):
         cn = int(rng.choice([1, 3]))
-        D = int(rng.choice([8, 16, 24, 32, 48, 50, 64, 96, 128, 160, 200, 256, 300]))
+        D = int(rng.choice([8, 16, 24, 32, 48, 50, 64, 80, 96, 128, 144, 160, 176, 192, 200, 218, 224, 256, 300]))  # every lane shape
         bs = int(rng.choice([0, 1, 3, 5, 7, 9, 11]))
         minD = int(rng.integers(-9, 10))
         mode = int(rng.choice([0, 1, 2, 3]))
@@ -87,6 +87,7 @@ def fuzz_sgbm(n, seed=77, log=print):
                 nb = int(rng.choice([1, 1, 3]))
                 got = m.compute(np.stack([left] * nb), np.stack([right] * nb)) if nb > 1 else m.compute(left, right)[None]
                 _count(br, "cost%d" % cost)
+                _count(br, "Dp%d" % m.geometry()["Dp"])  # which lane shape (16 lanes x Dp/32 registers from 96 on)
                 if nb > 1:
                     _count(br, "batched")
                 if cost != 2 and nb == 1 and mode != 2:

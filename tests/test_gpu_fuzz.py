@@ -28,7 +28,9 @@ def _run(fn, n, seeds, need):
 def test_fuzz_sgbm_slice(oracle):
     _run(fuzzers.fuzz_sgbm, 300, (401, 402, 403), dict(mode0=100, mode1=100, mode2=100, mode3=100, cost0=100, cost1=400,
                                                        cost2=400, batched=200, left_u16_regime=3, rgb_drift_input=50,
-                                                       gray_drift_input=50))
+                                                       gray_drift_input=50,
+                                                       # every lane shape of the volume layout (16 lanes x 3..8 / 12 registers)
+                                                       Dp96=40, Dp160=40, Dp192=40, Dp224=80, Dp256=20, Dp384=20))
 
 
 def test_fuzz_remap_slice(oracle):
