@@ -382,12 +382,25 @@ def config_c4(ca, synthetic, dev, nb=16, reps=3):
     torch.cuda.synchronize()
     rate = nb * reps / (time.perf_counter() - t0)
     m.status()
-    b_alg, _ = algorithmic_bytes_per_pair(W, H, D, 1)
+    b_alg, V = algorithmic_bytes_per_pair(W, H, D, 1)
+    # per-kernel table (hipEvents inside the library, each kernel alone on the GPU), like C5's per-stage table
+    m.set_profiling(True)
+    m.compute(L, R, out=out)
+    torch.cuda.synchronize()
+    table = stage_table(V, W * H, 1, "sgbm")
+    kernels = []
+    for st, ms in m.stage_times_ms().items():
+        if st in table and ms > 1e-3:
+            name, bpp, _ = table[st]
+            kernels.append(dict(stage=st, kernel=name, ms_per_call=ms, algorithmic_bytes_per_pair=bpp,
+                                hbm_frac=bpp * nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
     del m, L, R, out
     torch.cuda.empty_cache()
     return dict(workload="3840x2160 gray rectified pairs, numDisparities=256 blockSize=5 MODE_SGBM, %d pairs per call, "
                          "one batch at a time" % nb, pairs_per_s=rate, algorithmic_bytes_per_pair=b_alg,
-                achieved_GBs=b_alg * rate / 1e9, frac=b_alg * rate / 1e9 / HBM_PEAK_GBS)
+                achieved_GBs=b_alg * rate / 1e9, frac=b_alg * rate / 1e9 / HBM_PEAK_GBS, per_kernel=kernels,
+                note="a 4K pair is 78 bands deep: the first band pass is bound by the wavefront's critical path, not by "
+                     "throughput (12 pairs x 2 in flight or 8 x 3 give the same rate: profiles/r05_c4_batching.txt)")
 
 
 def depth_path_stages(st, imgs1, imgs2, W, H, D, cn, reps=5):
@@ -439,46 +452,49 @@ def depth_path_stages(st, imgs1, imgs2, W, H, D, cn, reps=5):
                         "hbm_frac": b * nb / (m * 1e-3) / 1e9 / HBM_PEAK_GBS} for n, m, b in rows]}
 
 
-def config_c5(ca, synthetic, dev, streams, nb=256):
-    """BASELINE.json configs[4]: 640x480 RGB, D=64, LR check on, speckle 100 / 2, the FULL get_depth path, batched."""
+def config_c5(ca, synthetic, dev, streams, nb=128):
+    """BASELINE.json configs[4]: 640x480 RGB, D=64, LR check on, speckle 100 / 2, the FULL get_depth path, batched.
+
+    The primary figure stays on the workload of rounds 1-3 so that rounds compare like for like: unrelated random
+    textures in the two cameras (every SGBM kernel costs the same whatever the content, but the matcher's output is all
+    speckles -- the worst case of the data-dependent speckle filter), 128 pairs per call.  A real stereo scene (textured
+    planes ray-cast through the rig's Brown models: smooth disparities, what the LR check and the speckle filter are
+    for) and 256 pairs per call are reported beside it under ``also_measured``."""
     import torch
     W, H, D = 640, 480, 64
     P = dict(minDisparity=0, numDisparities=D, blockSize=5, P1=8 * 3 * 25, P2=32 * 3 * 25, disp12MaxDiff=1, preFilterCap=0,
              uniquenessRatio=10, speckleWindowSize=100, speckleRange=2, mode=0)
-    # Input: a REAL stereo scene -- four textured planes ray-cast through the rig's Brown models (synthetic.render_plane_pair),
-    # so that the matcher finds the smooth disparities the LR check and the speckle filter are made for.  Rounds 1-3
-    # fed unrelated random textures (synthetic.scene_pair): every SGBM kernel costs the same there, but the matcher's
-    # output is all speckles, the worst case of the (data-dependent) speckle filter; that input is still reported below.
     rec = synthetic.rig(W, H)
     planes = [((0.3, 0.1, 1.0), 2.0), ((-0.2, 0.15, 1.0), 1.6), ((0.0, 0.0, 1.0), 2.5), ((0.1, -0.25, 1.0), 1.3)]
-    pairs = [synthetic.render_plane_pair(rec, n_, d_, seed=i)[:2] for i, (n_, d_) in enumerate(planes)]
+    scene = [synthetic.render_plane_pair(rec, n_, d_, seed=i)[:2] for i, (n_, d_) in enumerate(planes)]
     noise = [synthetic.scene_pair(100 + i, W, H, 3) for i in range(8)]
 
-    def batch(n, src=None):
-        src = pairs if src is None else src
+    def batch(n, src):
         return (torch.from_numpy(np.stack([src[i % len(src)][0] for i in range(n)])).to(dev),
                 torch.from_numpy(np.stack([src[i % len(src)][1] for i in range(n)])).to(dev))
-    B1, B2 = batch(nb)
+
+    def rate(n, src):
+        b1, b2 = batch(n, src)
+        out = depth_path_rate(ca, synthetic, P, b1, b2, streams, W, H, D, 3, max_depth=3.5, reps=6)
+        del b1, b2
+        return out
+    B1, B2 = batch(nb, noise)
     r = depth_path_rate(ca, synthetic, P, B1, B2, streams, W, H, D, 3, max_depth=3.5, reps=6)
-    r["workload"] = ("640x480 RGB pairs (rendered textured planes: a real stereo scene) through the whole get_depth path "
-                     "(rectify x2, SGBM numDisparities=64 blockSize=5 LR check on speckle 100/2, disp_to_depth, unrectify, "
-                     "undistort), %d pairs per call" % nb)
+    r["workload"] = ("640x480 RGB pairs (unrelated random textures in the two cameras: the input of rounds 1-3) through the "
+                     "whole get_depth path (rectify x2, SGBM numDisparities=64 blockSize=5 LR check on speckle 100/2, "
+                     "disp_to_depth, unrectify, undistort), %d pairs per call" % nb)
     st = ca.Stereo.load(synthetic.rig(W, H))
     st.set_stereo_matching(ca.SemiGlobalBlockMatching(dict(P, max_size=max(W, H))), max_depth=3.5)
     r["per_stage"] = depth_path_stages(st, B1, B2, W, H, D, 3)
     del B1, B2
-    # the same with 128 pairs per call (what rounds 2 and 3 reported): an image this small needs a deep batch to fill the
-    # band passes' last round of workgroups (9 bands x pairs over 512 places)
-    b1, b2 = batch(128)
-    r128 = depth_path_rate(ca, synthetic, P, b1, b2, streams, W, H, D, 3, max_depth=3.5, reps=6)
-    r["at_128_pairs_per_call"] = {k: r128[k] for k in ("pairs_per_s", "single_stream_pairs_per_s", "frac")}
-    del b1, b2
-    # the input of rounds 1-3 (unrelated random textures: the speckle filter's worst case), same pairs per call
-    n1, n2 = batch(nb, noise)
-    rn = depth_path_rate(ca, synthetic, P, n1, n2, streams, W, H, D, 3, max_depth=3.5, reps=6)
-    r["random_texture_input"] = dict({k: rn[k] for k in ("pairs_per_s", "single_stream_pairs_per_s", "frac")},
-                                     note="left / right images unrelated: the matcher's output is all speckles; only the "
-                                          "speckle filter's time depends on the content")
+    pick = lambda d: {k: d[k] for k in ("pairs_per_s", "single_stream_pairs_per_s", "frac")}  # noqa: E731
+    r["also_measured"] = {
+        "random_textures_at_256_pairs_per_call": pick(rate(256, noise)),
+        "rendered_scene_at_128_pairs_per_call": pick(rate(128, scene)),
+        "rendered_scene_at_256_pairs_per_call": pick(rate(256, scene)),
+        "note": "an image this small needs a deep batch to fill the band passes' last round of workgroups (9 bands x pairs "
+                "over 512 places); on a rendered scene the matcher's output is smooth and the speckle filter cheaper",
+    }
     return r
 
 
