@@ -1040,7 +1040,7 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     a.write_S = h->keep_S;
     CAMD_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
     // full passes: one workgroup per (pair, band); the row-parallel pass: the batch's rows in runs of R (sgbm_band.hpp)
-    dim3 grid(full ? h->nbands * batch : div_up((long long)batch * g.H, BAND_THREADS / g.lanes)), block(BAND_BLOCK);
+    dim3 grid(full ? h->nbands * batch : div_up((long long)batch * g.H, (CAMD_BAND_ROW_ALL_WAVES ? BAND_BLOCK : BAND_THREADS) / g.lanes)), block(BAND_BLOCK);
     const bool pad = g.Dp != g.D;
     // (the shapes that exist since round 5, nr = 3 / 5 / 6 / 7, are instantiated in their padded form only: the
     // unpadded one merely skips two masking operations per register, and D = Dp is the rare case there)

@@ -45,6 +45,14 @@ namespace camd {
 #ifndef CAMD_BAND_MIN_WAVES
 #define CAMD_BAND_MIN_WAVES 4                            // occupancy target (waves per SIMD) of the D <= 128 instantiations
 #endif
+// the row-parallel (!FULL) pass has no helper duty: 1 = all eight waves of its workgroups compute (rows per workgroup =
+// BAND_BLOCK / LANES), 0 = the wave that would be the helper just exits (round 1-4)
+#ifndef CAMD_BAND_ROW_ALL_WAVES
+#define CAMD_BAND_ROW_ALL_WAVES 0
+#endif
+#ifndef CAMD_BAND_ROW_MIN_WAVES
+#define CAMD_BAND_ROW_MIN_WAVES CAMD_BAND_MIN_WAVES      // occupancy target of the row-parallel pass (it needs 66 VGPRs)
+#endif
 static constexpr int BAND_THREADS = 64 * CAMD_BAND_COMPUTE_WAVES;  // compute threads
 static constexpr int BAND_BLOCK = BAND_THREADS + 64;     // + one helper wave
 static constexpr int BAND_HELPER_WAVE = CAMD_BAND_HELPER_WAVE;
@@ -137,7 +145,7 @@ template <int LANES> struct WtaPad { static constexpr int Q = (LANES * 16) % 128
 // for D % 8 == 0: disparities are scanned 8 at a time, each of the 8 lane slots keeps the LAST d attaining the
 // minimum, the winner is the smallest of those positions.  With a single minimum that is the ordinary winner, so the
 // rule is only evaluated when some pixel of the wave has its first and last minimum at different d.
-template <int LANES, int NR, bool TIE8 = false>
+template <int LANES, int NR, bool TIE8 = false, int NTH = BAND_THREADS>
 __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[NR], const uint32_t (&dpk)[NR], uint4* wS,
                                               const Geom& g, int ctid, int grp, int li, int t, bool act,
                                               uint32_t& cap_key, uint32_t& cap_nb)
@@ -183,7 +191,7 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[NR], const uin
     }
     // park S so that S[best-1], S[best+1] can be picked without a select tree
     // plane v of the parked vectors: [group][LANES + pad] uint4 (see WtaPad); WS_PLANE uint4 per plane
-    constexpr int GST = LANES + WtaPad<LANES>::Q, WS_PLANE = (BAND_THREADS / LANES) * GST;
+    constexpr int GST = LANES + WtaPad<LANES>::Q, WS_PLANE = (NTH / LANES) * GST;
     lds_st_regs<NR>(wS, grp * GST + li, WS_PLANE, s);
     // (2) uniqueness: S[d]*(100-u) < minS*100 for some |d-best| > 1
     //     <=>  min over those d of S[d]  <=  T = floor((minS*100 - 1) / (100-u)); the division by the launch
@@ -256,10 +264,11 @@ __device__ __forceinline__ void band_wta_flush(const BandArgs& a, const Geom& g,
 // MODE: 0 = first pass (S written), 2 = final (S read, WTA; S stored only for the parity hook)
 // DIAG = false (MODE_HH4): the two diagonal directions are left out (their slots travel as zeros)
 template <int LANES, int NR, bool FULL, int MODE, bool PAD, bool DIAG = true, bool TIE8 = false>
-__global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? CAMD_BAND_MIN_WAVES : 2) void k_band(BandArgs a, Geom g)
+__global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES : CAMD_BAND_ROW_MIN_WAVES) : 2) void k_band(BandArgs a, Geom g)
 {
     constexpr int NQ = (NR + 3) / 4;  // 16-byte LDS slots / u64 edge-record pairs per lane and vector
-    constexpr int R = BAND_THREADS / LANES;
+    constexpr int NTH = (!FULL && CAMD_BAND_ROW_ALL_WAVES) ? BAND_BLOCK : BAND_THREADS;  // compute threads of a workgroup
+    constexpr int R = NTH / LANES;
     constexpr int EVEC = 6 * NQ;     // u64 per lane per column: V (2NQ), Dg (2NQ), A (2NQ)
     constexpr int CPB = 64 / LANES;  // columns the helper wave fetches per batch
     constexpr int RING = FULL ? BAND_RING : BAND_RING_ROWS;
@@ -289,9 +298,10 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? CAMD_BAND_MIN_WAVES : 2) void
     // compute thread index).  Which wave helps decides which SIMD carries one compute wave less (see
     // tools/microtests/wave_simd_placement.hip)
     const int wv = threadIdx.x >> 6;
-    const bool helper = wv == BAND_HELPER_WAVE;                    // wave-uniform
+    const bool helper = (FULL || !CAMD_BAND_ROW_ALL_WAVES) && wv == BAND_HELPER_WAVE;  // wave-uniform
     if (!FULL && helper) return;
-    const int ctid = helper ? (int)(threadIdx.x & 63) : (((wv > BAND_HELPER_WAVE ? wv - 1 : wv) << 6) | (int)(threadIdx.x & 63));
+    const int ctid = (!FULL && CAMD_BAND_ROW_ALL_WAVES) ? (int)threadIdx.x
+                     : helper ? (int)(threadIdx.x & 63) : (((wv > BAND_HELPER_WAVE ? wv - 1 : wv) << 6) | (int)(threadIdx.x & 63));
     const int grp = ctid / LANES, li = ctid % LANES;
     const int W1 = g.W1, H = g.H;
     // FULL: row `grp` of band `band` of pair ticket % npairs.  !FULL: rows are independent, so the workgroups cut the
@@ -459,7 +469,9 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? CAMD_BAND_MIN_WAVES : 2) void
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef CAMD_BAND_DBG_NOBARRIER
             __builtin_amdgcn_s_barrier();
+#endif
         }
         return;
     }
@@ -535,7 +547,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? CAMD_BAND_MIN_WAVES : 2) void
                 if (MODE != 2 || a.write_S) {
                     st_regs<NR>(Srow + cell_off(xi), s);
                 }
-                if (MODE == 2) band_wta_step<LANES, NR, TIE8>(s, dpk, wS, g, ctid, grp, li, t, true, cap_key, cap_nb);
+                if (MODE == 2) band_wta_step<LANES, NR, TIE8, NTH>(s, dpk, wS, g, ctid, grp, li, t, true, cap_key, cap_nb);
             }
             if (MODE == 2 && ((t & (LANES - 1)) == LANES - 1 || t == nsteps - 1)) {
                 // lane li captured the pixel of step t - ((t mod LANES) - li)
@@ -577,7 +589,12 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? CAMD_BAND_MIN_WAVES : 2) void
                 }
                 // LDS-only barrier (a __syncthreads() would drain the C/S prefetch ring)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if defined(CAMD_BAND_DBG_NOBARRIER) && !defined(CAMD_MEASUREMENT_BUILD)
+#error "CAMD_BAND_DBG_NOBARRIER produces wrong results: measurement builds only (define CAMD_MEASUREMENT_BUILD too)"
+#endif
+#ifndef CAMD_BAND_DBG_NOBARRIER  // (measurement only: what the per-step workgroup barrier costs)
                 __builtin_amdgcn_s_barrier();
+#endif
             }
         }
     }

@@ -82,6 +82,30 @@ __device__ __forceinline__ uint32_t lane_window_sum(uint32_t p)
     return p + wave_shr<1>(w10);
 }
 
+// The same window as a difference of wave-wide inclusive prefix sums: six DPP adds (row_shr 1, 2, 4, 8, row_bcast 15 / 31)
+// + one ds_bpermute for P(l - K) instead of K - 1 single-lane shifts.  For K >= 9 (the reference's block 11: ten
+// shifts + five adds per packed register).  The halves cannot carry: a prefix over 64 lanes of pixel costs is at most
+// 64 * CN * (2 * CAMD_MAX_FTZERO + 63) < 65536.  `back` = byte address of lane l - K for ds_bpermute, `live` = l >= K.
+// Measured in round 5 on the reference's default matcher (block 11 x RGB, 64 pairs of 1000 x 562): 9.7 ms either way
+// (bit-exact; tools/gpu_default_batch.py) -- at block 11 the kernel is not bound by the count of its window operations
+// (four waves per SIMD at 128 VGPRs for the 11-row ring, 27 ds_read_b128 per row).  Off by default.
+#ifndef CAMD_COST_SCAN_WINDOW
+#define CAMD_COST_SCAN_WINDOW 0
+#endif
+static_assert(64 * 3 * (2 * CAMD_MAX_FTZERO + 63) < 65536, "a 64-lane prefix of pixel costs must fit a 16-bit half");
+__device__ __forceinline__ uint32_t lane_window_sum_scan(uint32_t p, int back, bool live)
+{
+    uint32_t s = p;
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, false);  // row_shr:1
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false);  // row_shr:2
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false);  // row_shr:4
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xf, false);  // row_shr:8
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute(back, (int)s);
+    return s - (live ? prev : 0u);
+}
+
 // Row ranges the cost volume is built for.  Every mode but MODE_SGBM_3WAY has ONE range, the image; 3WAY has one per
 // stripe (cv2 computes its stripes independently: the vertical box window is clamped at the stripe's first row, and
 // the volume of a stripe is stored as a "virtual pair" of its own, so that the aggregation kernels see independent
@@ -278,6 +302,8 @@ __global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t*
     const bool first_col = xo == 0;
     uint16_t* const outp = Cout + (size_t)vpair * vol_stride + (size_t)(writer ? xo : 0) * g.Dp + d0;
 
+    const int win_back = ((lane - K) & 63) << 2;
+    const bool win_live = lane >= K;
     const uint32_t p2 = dup16((uint32_t)g.P2);
     uint32_t acc[NP], ring[K][NP];
 #pragma unroll
@@ -341,7 +367,8 @@ __global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t*
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
                     const uint32_t pp = (cost[2 * k] | (cost[2 * k + 1] << 16)) & keep[k];
-                    const uint32_t T = lane_window_sum<K>(pp);
+                    const uint32_t T = (CAMD_COST_SCAN_WINDOW && K >= 9) ? lane_window_sum_scan(pp, win_back, win_live)
+                                                                         : lane_window_sum<K>(pp);
                     const uint32_t old = ring[u][k];
                     ring[u][k] = T;
                     if (SAT) {
