@@ -530,13 +530,13 @@ static constexpr uint32_t KEY_INIT = 0x7fff0000u;
 // (CostType)L (computeDisparitySGBM_HH4); 2: the same of saturate(L) (the 3-way loop) -- and every total is carried
 // as S + 32768 in an unsigned half, so that all comparisons below order the same way; `bias` turns them back into
 // values where the arithmetic needs them.
-template <int LANES, int NR, bool EXACT = false>
-__global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, int16_t* __restrict__ disp,
-                                             size_t disp_pitch_e, size_t disp_stride_e, Geom g,
-                                             size_t vol_stride, int nvol, size_t dir_stride, int tie_lanes,
-                                             int combine = 0, const uint32_t* __restrict__ neg = nullptr, int vp = 0)
+// (the body of k_wta for row y of pair `pair`; the persistent exact kernel of sgbm_exact.hpp calls it row after row)
+template <int LANES, int NR, bool EXACT>
+__device__ __forceinline__ void wta_row(const uint16_t* __restrict__ Sv, int16_t* __restrict__ disp,
+                                        size_t disp_pitch_e, size_t disp_stride_e, const Geom& g,
+                                        size_t vol_stride, int nvol, size_t dir_stride, int tie_lanes,
+                                        int combine, int y, int pair)
 {
-    if (EXACT && !neg[vp]) return;
     constexpr int bias = EXACT ? 32768 : 0;
     constexpr uint32_t key_init = EXACT ? 0xffff0000u : KEY_INIT;
     constexpr int max_cost_b = MAX_COST + bias;
@@ -544,7 +544,6 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);          // [W]
     int16_t* d1row = reinterpret_cast<int16_t*>(keys + g.W);     // [W]
     constexpr int GROUPS = 256 / LANES;
-    const int y = blockIdx.x, pair = blockIdx.y;
     const int li = threadIdx.x % LANES, grp = threadIdx.x / LANES;
     const int INVALID_SCALED = (g.minD - 1) * 16;
 
@@ -712,6 +711,15 @@ __global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, in
     }
 }
 
+template <int LANES, int NR>
+__global__ __launch_bounds__(256) void k_wta(const uint16_t* __restrict__ Sv, int16_t* __restrict__ disp,
+                                             size_t disp_pitch_e, size_t disp_stride_e, Geom g,
+                                             size_t vol_stride, int nvol, size_t dir_stride, int tie_lanes)
+{
+    wta_row<LANES, NR, false>(Sv, disp, disp_pitch_e, disp_stride_e, g, vol_stride, nvol, dir_stride, tie_lanes, 0,
+                              (int)blockIdx.x, (int)blockIdx.y);
+}
+
 __global__ void k_fill_s16(int16_t* p, size_t pitch_e, size_t stride_e, int W, int H, int value)
 {
     int x = blockIdx.x * 256 + threadIdx.x;
@@ -792,6 +800,8 @@ struct camd_sgbm {
     size_t erec_stride;
     unsigned long long* E;
     uint32_t *flags, *ticket, *err, *keys;
+    uint32_t* xbar;       // grid-barrier counter of the exact path's persistent kernel (sgbm_exact.hpp)
+    int num_cus;          // compute units of the device the handle lives on
     uint32_t* err_host;   // pinned mirror of *err, refreshed by an async copy after every band-path compute
     int16_t* d1;
     uint32_t epoch;
@@ -1100,9 +1110,9 @@ __global__ __launch_bounds__(256) void k_poison_flagged(int16_t* __restrict__ ra
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, 2u);
 }
 
-// the aggregation + winner-take-all of ONE (virtual) pair in int arithmetic (sgbm_exact.hpp); both kernels return at
-// once unless the volume is flagged.  dst: the raw disparity image of that (virtual) pair.
-static int launch_exact(const camd_sgbm* h, int vp, int16_t* dst, hipStream_t st)
+// the aggregation + winner-take-all in int arithmetic (sgbm_exact.hpp) of every FLAGGED (virtual) pair of the batch, in
+// one launch that returns at once when nothing is flagged.  dst: the raw disparity image of (virtual) pair 0.
+static int launch_exact(const camd_sgbm* h, int nvolumes, int16_t* dst, size_t stride_e, size_t n_e, hipStream_t st)
 {
     const Geom& g = h->ga;
     // directions in the order OpenCV adds them up (it matters once sums saturate with negative terms in play)
@@ -1112,36 +1122,41 @@ static int launch_exact(const camd_sgbm* h, int vp, int16_t* dst, hipStream_t st
     const int (*dirs)[2] = g.mode == CAMD_MODE_HH4 ? d_hh4 : (g.mode == CAMD_MODE_SGBM_3WAY ? d_3way : d_sgbm);
     const int nd = g.npaths;
     ScanDirs sd;
-    int maxlines = 0;
     for (int i = 0; i < 8; i++) {
         const int k = i < nd ? i : 0;
         sd.dx[i] = dirs[k][0];
         sd.dy[i] = dirs[k][1];
         sd.nlines[i] = sd.dy[i] == 0 ? g.H : (sd.dx[i] == 0 ? g.W1 : g.W1 + g.H - 1);
-        if (i < nd && sd.nlines[i] > maxlines) maxlines = sd.nlines[i];
     }
     sd.dir_stride = h->vol_elems;  // (int elements)
-    const int16_t* C = reinterpret_cast<const int16_t*>(h->C) + (size_t)vp * h->vol_elems;
-    int32_t* L = h->Lx;
     const bool way3 = g.mode == CAMD_MODE_SGBM_3WAY;
-    dim3 grid(div_up((long long)maxlines * g.lanes, 256), 1, nd);
-#define CAMD_XSCAN(LN, NVV)                                                                                        \
-    do {                                                                                                           \
-        if (way3) hipLaunchKernelGGL((k_scan_exact<LN, NVV, true>), grid, dim3(256), 0, st, C, L, g, sd, h->cost_neg, vp, 0); \
-        else hipLaunchKernelGGL((k_scan_exact<LN, NVV, false>), grid, dim3(256), 0, st, C, L, g, sd, h->cost_neg, vp,         \
-                                g.mode == CAMD_MODE_HH4 ? 1 : 0);                                                             \
+    ExactArgs a;
+    a.C = reinterpret_cast<const int16_t*>(h->C);
+    a.Lx = h->Lx;
+    a.dst = dst;
+    a.vol_stride = h->vol_elems;
+    a.dst_stride_e = stride_e;
+    a.dst_pitch_e = (size_t)g.W;
+    a.dst_n = n_e;
+    a.neg = h->cost_neg;
+    a.bar = h->xbar;
+    a.err = h->err;
+    a.nvol = nvolumes;
+    a.nd = nd;
+    a.tie_lanes = way3 ? h->way3_simd_lanes : 0;
+    a.combine = g.mode == CAMD_MODE_HH4 ? 1 : (way3 ? 2 : 0);
+    a.min_as_int = g.mode == CAMD_MODE_HH4 ? 1 : 0;
+    a.invalid = (g.minD - 1) * 16;
+    CAMD_HIP(hipMemsetAsync(h->xbar, 0, 4, st));
+    const size_t lds = align_up((size_t)g.W * 6, 16);
+    const dim3 grid(h->num_cus > 0 ? h->num_cus : 256);  // one workgroup per compute unit: all resident at once
+#define CAMD_XALL(LN, NRR)                                                                                          \
+    do {                                                                                                            \
+        if (way3) hipLaunchKernelGGL((k_exact_all<LN, NRR, true>), grid, dim3(256), lds, st, a, g, sd);             \
+        else hipLaunchKernelGGL((k_exact_all<LN, NRR, false>), grid, dim3(256), lds, st, a, g, sd);                 \
     } while (0)
-    CAMD_FOR_SHAPE(g, CAMD_XSCAN);
-#undef CAMD_XSCAN
-    CAMD_LAUNCH_CHECK();
-    const int tie_lanes = way3 ? h->way3_simd_lanes : 0;
-    const int combine = g.mode == CAMD_MODE_HH4 ? 1 : (way3 ? 2 : 0);
-    size_t lds = align_up((size_t)g.W * 6, 16);
-#define CAMD_XWTA(LN, NVV)                                                                                          \
-    hipLaunchKernelGGL((k_wta<LN, NVV, true>), dim3(g.H, 1), dim3(256), lds, st, reinterpret_cast<const uint16_t*>(L), \
-                       dst, (size_t)g.W, (size_t)0, g, (size_t)0, nd, sd.dir_stride, tie_lanes, combine, h->cost_neg, vp)
-    CAMD_FOR_SHAPE(g, CAMD_XWTA);
-#undef CAMD_XWTA
+    CAMD_FOR_SHAPE(g, CAMD_XALL);
+#undef CAMD_XALL
     CAMD_LAUNCH_CHECK();
     return CAMD_OK;
 }
@@ -1238,9 +1253,17 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     h->cost_neg = h->cost_ovf ? h->cost_ovf + nvol : nullptr;
     if (e == hipSuccess) e = hipMemset(h->cost_ovf, 0, nvol * 8);
     h->may_overflow = params_may_overflow(g);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->ticket, 8);
-    if (e == hipSuccess) e = hipMemset(h->ticket, 0, 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->ticket, 16);
+    if (e == hipSuccess) e = hipMemset(h->ticket, 0, 16);
     h->err = h->ticket ? h->ticket + 1 : nullptr;
+    h->xbar = h->ticket ? h->ticket + 2 : nullptr;
+    {
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            h->num_cus = ncu;
+        else
+            (void)hipGetLastError();
+    }
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->err_host, 4, hipHostMallocDefault);
     if (e == hipSuccess) *h->err_host = 0;
     size_t sws = speckle_ws_bytes(width, height, max_batch);
@@ -1688,11 +1711,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
             CAMD_HIP(hipMemcpyAsync(h->err_host, h->err, 4, hipMemcpyDeviceToHost, st));
             return CAMD_OK;
         }
-        for (int vp = 0; vp < nvolumes; vp++) {
-            int rc = launch_exact(h, vp, dst + (size_t)vp * stride_e, st);
-            if (rc != CAMD_OK) return rc;
-        }
-        return CAMD_OK;
+        return launch_exact(h, nvolumes, dst, stride_e, n_e, st);
     };
 
     MARK(ST_WTA);

@@ -67,15 +67,15 @@ __device__ __forceinline__ int sat16i(int v) { return v < -32768 ? -32768 : (v >
 // STORE_SAT: how L is narrowed to int16 for the recursion itself -- false: the (CostType) cast of
 // computeDisparitySGBM / computeDisparitySGBM_HH4 (wraps), true: the saturate_cast of the 3-way loop
 // (oracle/sgbm_ref.c:768-774), whose minimum is taken over the narrowed values.
+// (`dir` = index into sd, `unit` = which run of 256 / LANES lines of that direction this workgroup scans)
 template <int LANES, int NR, bool STORE_SAT>
-__global__ __launch_bounds__(256) void k_scan_exact(const int16_t* __restrict__ Cv, int32_t* __restrict__ Lout, Geom g,
-                                                    ScanDirs sd, const uint32_t* __restrict__ neg, int vp, int min_as_int)
+__device__ __forceinline__ void scan_exact_unit(const int16_t* __restrict__ Cv, int32_t* __restrict__ Lout, const Geom& g,
+                                                const ScanDirs& sd, int dir, int unit, int min_as_int)
 {
-    if (!neg[vp]) return;
     constexpr int NE = 2 * NR;  // disparities per lane
-    const int dx = sd.dx[blockIdx.z], dy = sd.dy[blockIdx.z], nlines = sd.nlines[blockIdx.z];
-    int32_t* __restrict__ Lv = Lout + (size_t)blockIdx.z * sd.dir_stride;
-    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int dx = sd.dx[dir], dy = sd.dy[dir], nlines = sd.nlines[dir];
+    int32_t* __restrict__ Lv = Lout + (size_t)dir * sd.dir_stride;
+    const int tid = unit * 256 + threadIdx.x;
     const int line = tid / LANES, li = tid % LANES;
     if (line >= nlines) return;  // (whole groups: 256 % LANES == 0)
     const int W1 = g.W1, H = g.H;
@@ -147,6 +147,88 @@ __global__ __launch_bounds__(256) void k_scan_exact(const int16_t* __restrict__ 
         for (int v = 0; v < NR; v++) o[v] = make_int2(Lint[2 * v], Lint[2 * v + 1]);
 #pragma unroll
         for (int j = 0; j < NE; j++) { Lp[j] = L[j]; c[j] = cn[j]; }
+    }
+}
+
+// ---- one launch for the whole batch ------------------------------------------------------------------------------
+// Rounds 3-4 queued two launches per volume (scan, winner-take-all) that returned at once unless the volume was flagged:
+// 128 empty launches per 64-pair batch of the reference's default matcher, whose parameters merely ALLOW an overflow
+// (0.6 ms of a 27 ms batch).  Now ONE persistent kernel walks the flags: nothing flagged (the normal case) -> every
+// workgroup reads nvol words and leaves.  A flagged volume is scanned by all workgroups together (units of 256 / LANES
+// lines, grid-stride), a grid-wide barrier, its rows are decided (grid-stride), a second barrier (the one set of
+// per-direction volumes is reused by the next flagged volume).  The grid is one workgroup per compute unit, so all of it
+// is resident once whatever else runs on the device has made room; the barrier is a monotonic counter (zeroed by the
+// host before the launch) with agent-scope fences on both sides, and every wait is bounded: on expiry the error word is
+// raised (camd_sgbm_status / the next compute report it) and the flagged volumes are written as invalid.
+struct ExactArgs {
+    const int16_t* C;      // volume 0
+    int32_t* Lx;           // npaths per-direction int volumes (one set)
+    int16_t* dst;          // raw disparity image of volume 0
+    size_t vol_stride;     // int16 elements between volumes of C
+    size_t dst_stride_e;   // elements between the disparity images of consecutive volumes
+    size_t dst_pitch_e;
+    size_t dst_n;          // elements of one disparity image
+    const uint32_t* neg;   // per-volume flags
+    uint32_t* bar;         // grid barrier counter
+    uint32_t* err;
+    int nvol, nd, tie_lanes, combine, min_as_int, invalid;
+};
+static constexpr uint32_t EXACT_SPIN_LIMIT = 1u << 23;  // seconds of s_sleep polling: a flagged 4K volume takes ~0.1 s a phase
+
+template <int LANES, int NR, bool STORE_SAT>
+__global__ __launch_bounds__(256) void k_exact_all(ExactArgs a, Geom g, ScanDirs sd)
+{
+    uint32_t target = 0;
+    bool dead = false;
+    auto grid_sync = [&]() {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();  // release: this workgroup's stores reach the device-wide level before it is counted
+            target += gridDim.x;
+            atomicAdd(a.bar, 1u);
+            uint32_t spins = 0;
+            while (!dead && __hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > EXACT_SPIN_LIMIT) {
+                    atomicOr(a.err, 1u);
+                    dead = true;
+                }
+            }
+            __threadfence();  // acquire: the other workgroups' stores are visible from here on
+        }
+        __syncthreads();
+    };
+    int units[8], total = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        units[d] = d < a.nd ? (sd.nlines[d] * LANES + 255) / 256 : 0;
+        total += units[d];
+    }
+    bool any = false;
+    for (int vp = 0; vp < a.nvol; vp++) {
+        if (!a.neg[vp]) continue;  // (the same decision in every workgroup: the flags were written by earlier kernels)
+        any = true;
+        const int16_t* C = a.C + (size_t)vp * a.vol_stride;
+        for (int u = blockIdx.x; u < total; u += gridDim.x) {
+            int dir = 0, rest = u;
+            while (rest >= units[dir]) rest -= units[dir++];
+            scan_exact_unit<LANES, NR, STORE_SAT>(C, a.Lx, g, sd, dir, rest, a.min_as_int);
+        }
+        grid_sync();
+        for (int y = blockIdx.x; y < g.H; y += gridDim.x) {
+            wta_row<LANES, NR, true>(reinterpret_cast<const uint16_t*>(a.Lx), a.dst + (size_t)vp * a.dst_stride_e, a.dst_pitch_e,
+                                     (size_t)0, g, (size_t)0, a.nd, sd.dir_stride, a.tie_lanes, a.combine, y, 0);
+            __syncthreads();  // the row's LDS scratch is reused by the next row
+        }
+        grid_sync();
+    }
+    // a barrier that gave up: never hand back what may have been computed from half-written volumes
+    if (any && (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) {
+        for (int vp = 0; vp < a.nvol; vp++) {
+            if (!a.neg[vp]) continue;
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.dst_n; i += (size_t)gridDim.x * 256)
+                a.dst[(size_t)vp * a.dst_stride_e + i] = (int16_t)a.invalid;
+        }
     }
 }
 

@@ -99,3 +99,43 @@ def test_refused_loudly_without_the_exact_path(oracle):
     got = m.compute(L, R).cpu().numpy()
     assert np.array_equal(got[1], oracle.sgbm_compute(*bad, **p))
     m.status()
+
+
+def test_exact_path_on_two_streams_at_once(oracle):
+    """The exact path is ONE persistent kernel per batch with a grid-wide barrier between the scan and the winner-take-all
+    of each flagged volume (sgbm_exact.hpp).  Two handles on two streams, both with several flagged volumes in their
+    batches, running at the same time -- their barriers are independent counters, neither may wait for the other -- next
+    to a third stream that keeps the chip busy with an ordinary batch.  Every pair must equal the oracle."""
+    import torch
+    case = CASES[3]  # 16 lanes, padded D = 200 (7 registers per lane)
+    H, W, D, bs, cn = case[:5]
+    p = _params(case, 0)
+    drift = [synthetic.drift_pair(H, W, cn, split=s, seed=i) for i, s in enumerate((0.5, 0.3, 0.7))]
+    plain = [synthetic.rectified_pair(seed=9 + i, H=H, W=W, D=D, cn=cn) for i in range(2)]
+    pairs = [drift[0], plain[0], drift[1], drift[2], plain[1]]
+    want = [oracle.sgbm_compute(a, b, **p) for a, b in pairs]
+    L = torch.from_numpy(np.stack([a for a, _ in pairs])).cuda()
+    R = torch.from_numpy(np.stack([b for _, b in pairs])).cuda()
+    ms = [ca.StereoSGBM_create(**p) for _ in range(2)]
+    for m in ms:
+        m.set_option("path", 2)
+        m.compute(L, R)  # workspaces allocated before the concurrent part
+    busy = ca.StereoSGBM_create(minDisparity=0, numDisparities=128, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1)
+    bl, br = synthetic.rectified_batch_torch(3, 16, 360, 960, 128, 3, "cuda")
+    busy.compute(bl, br)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [None, None]
+    for rep in range(4):
+        with torch.cuda.stream(streams[2]):
+            busy.compute(bl, br)
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                outs[i] = ms[i].compute(L, R)
+    torch.cuda.synchronize()
+    for m in ms + [busy]:
+        m.status()
+    for i in range(2):
+        got = outs[i].cpu().numpy()
+        for k in range(len(pairs)):
+            assert np.array_equal(got[k], want[k]), (i, k)
