@@ -1,8 +1,9 @@
 """ctypes front-end of the CPU oracle (oracle/*.c).
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, ``__graft_entry__.smoke()`` and the
-``cpu_baseline`` leg of bench.py -- never from ``calibrating_amd``.  PARITY UNPINNED (cv2 is not
-available where this was written and the reference holds no golden vectors; see oracle/oracle.h).
+``cpu_baseline`` leg of bench.py -- never from ``calibrating_amd``.  PARITY UNPINNED against cv2 (cv2 is not
+available where this was written and the reference holds no golden vectors; see oracle/oracle.h); the restatements of
+the reference's own NumPy are pinned by the reference's own run (tests/golden/reference_plumbing.npz).
 """
 import ctypes
 import os

@@ -19,6 +19,10 @@
  *   calibrating/stereo_camera.py:430-431      cv2.undistort
  *   calibrating/utils.py:173-200              rotate_depth_by_remap (cv2.remap INTER_NEAREST)
  * It is pinned only by analytic known-answer tests and by an independent NumPy model in tests/.
+ * The parts that restate the REFERENCE's own NumPy (depth_ref.c; oracle/pointcloud_ref.py) are pinned since round 5 by
+ * outputs of the reference itself: tests/golden/reference_plumbing.npz, made by running /root/reference/calibrating
+ * unmodified with these functions standing in for its cv2 entry points (tests/golden/make_reference_golden.py) --
+ * which pins the reference's Python around the entry points, not OpenCV's arithmetic behind them.
  */
 #ifndef CALIBRATING_ORACLE_H
 #define CALIBRATING_ORACLE_H
