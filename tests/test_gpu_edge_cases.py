@@ -237,3 +237,51 @@ def test_matcher_keeps_a_handle_per_image_shape(oracle):
     m.setUniquenessRatio(5)
     assert len(m._cache) == 0
     assert np.array_equal(m.compute(*a), oracle.sgbm_compute(*a, **dict(p, uniquenessRatio=5)))
+
+
+def test_cu_mask_stream_and_split_phases_give_the_same_disparity(oracle):
+    """camd_stream_create_cu_mask (a HIP stream restricted to a subset of the compute units) and CAMD_OPT_PHASES (one
+    compute queued as its cost half and its aggregation half, here on two different masked streams with an event in
+    between): placement and splitting must not change a bit of the result."""
+    import ctypes
+    from calibrating_amd import _native
+    p = dict(minDisparity=0, numDisparities=96, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, uniquenessRatio=10)
+    a = synthetic.rectified_pair(seed=4, H=96, W=400, D=96, cn=3)
+    want = oracle.sgbm_compute(*a, **p)
+    lib = _native.lib()
+    streams, handles = [], []
+    for lo, hi in ((0, 96), (96, 256)):
+        words = (ctypes.c_uint32 * 8)()
+        for i in range(lo, hi):
+            words[i // 32] |= 1 << (i % 32)
+        st = ctypes.c_void_p()
+        _native.check(lib.camd_stream_create_cu_mask(words, 8, ctypes.byref(st)))
+        handles.append(st)
+        streams.append(torch.cuda.ExternalStream(st.value, device=torch.device("cuda", 0)))
+    L, R = (torch.from_numpy(x).cuda() for x in a)
+    m = ca.StereoSGBM_create(**p)
+    m.set_option("path", 2)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(streams[0]):           # everything on 96 CUs
+        whole = m.compute(L, R)
+    streams[0].synchronize()
+    assert np.array_equal(whole.cpu().numpy(), want)
+    out = torch.empty_like(whole)
+    with torch.cuda.stream(streams[0]):           # the cost volume on 96 CUs ...
+        m.set_option("phases", 1)
+        m.compute(L, R, out=out)
+        ev = streams[0].record_event()
+    with torch.cuda.stream(streams[1]):           # ... aggregation and post on the other 160
+        streams[1].wait_event(ev)
+        m.set_option("phases", 2)
+        m.compute(L, R, out=out)
+    streams[1].synchronize()
+    m.set_option("phases", 3)
+    m.status()
+    assert np.array_equal(out.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        m.set_option("phases", 0)
+    del streams
+    torch.cuda.synchronize()
+    for st in handles:
+        _native.check(lib.camd_stream_destroy(st))
