@@ -65,9 +65,9 @@ class StereoSGBM:
         'phases': what a compute() call queues, 1 = the cost volume only, 2 = aggregation + post only (on the volume the
         previous phase-1 call built), 3 = both (default) -- for callers that pipeline the two over two streams."""
         opt = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3, "way3_simd_lanes": 4, "exact": 5, "phases": 6}[option]
-        self._options[opt] = int(value)
         for hd, _, _ in self._cache.values():
-            _native.check(_native.lib().camd_sgbm_set_option(hd, opt, int(value)))
+            _native.check(_native.lib().camd_sgbm_set_option(hd, opt, int(value)))  # (a refused value is not remembered)
+        self._options[opt] = int(value)
         return self
 
     def status(self):
