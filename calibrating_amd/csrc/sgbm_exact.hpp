@@ -61,9 +61,9 @@ __device__ __forceinline__ int group_min_i32(int v)
 
 __device__ __forceinline__ int sat16i(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 
-// One direction per blockIdx.z (sd), ONE volume `vp`; L of direction z goes to Lout + z * sd.dir_stride AS INT, before
+// One direction `dir` of sd, ONE volume; L of that direction goes to Lout + dir * sd.dir_stride AS INT, before
 // it is narrowed: OpenCV's sums S += L0 + L1 + L2 + L3 take the int values, not the stored CostType ones, and once C
-// is below -32768 + P2 the two differ (k_wta<EXACT> narrows as the mode's own loop does).
+// is below -32768 + P2 the two differ (wta_row<EXACT> narrows as the mode's own loop does).
 // STORE_SAT: how L is narrowed to int16 for the recursion itself -- false: the (CostType) cast of
 // computeDisparitySGBM / computeDisparitySGBM_HH4 (wraps), true: the saturate_cast of the 3-way loop
 // (oracle/sgbm_ref.c:768-774), whose minimum is taken over the narrowed values.

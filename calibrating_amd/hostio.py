@@ -79,13 +79,19 @@ class Sink:
         self.side.wait_event(self.main.record_event())
         with torch.cuda.device(self.device), torch.cuda.stream(self.side):
             self.staged[key] = _start(t)
+            self.done = self.side.record_event()  # everything sent so far has arrived once this event has passed
         t.record_stream(self.side)
 
-    def collect(self):
+    def collect(self, own_copies_only=False):
+        """``own_copies_only``: wait for THIS call's copies alone (an event on the side stream), not for whatever was
+        queued on the two streams afterwards -- what lets ``Stereo.get_depth_async`` keep several calls in flight."""
         if not PINNED:
             return {k: t.cpu().numpy() for k, t in self.staged.items()}
-        self.side.synchronize()
-        self.main.synchronize()
+        if own_copies_only and getattr(self, "done", None) is not None:
+            self.done.synchronize()
+        else:
+            self.side.synchronize()
+            self.main.synchronize()
         out = {k: h.numpy() for k, h in self.staged.items()}
         out.update({k: t.cpu().numpy() for k, t in self.late.items()})
         return out

@@ -32,6 +32,21 @@ _P = dict(magic=(0, 1), K=(1, 10), R1=(10, 19), R2=(19, 28), cam1_K=(28, 37), ca
           cam2_xy=(53, 55), xy=(55, 57), t=(57, 60), nD=(60, 61))
 
 
+class PendingDepth:
+    """What ``Stereo.get_depth_async`` returns: ``result()`` -> the dict of ``get_depth`` (waits for this call's copies;
+    device-tensor calls have nothing to wait for).  A device-side failure of the matcher (a bounded wait that expired)
+    is not checked here -- that would wait for every later call too; the matcher's next ``compute`` / ``status()`` raise."""
+
+    def __init__(self, result, sink):
+        self._result, self._sink = result, sink
+
+    def result(self):
+        if self._sink is not None:
+            self._result.update(self._sink.collect(own_copies_only=True))
+            self._sink = None
+        return self._result
+
+
 class Stereo:
     DUMP_ATTRS = ["R", "t", "retval"]
     MAX_DEPTH = 1000
@@ -362,7 +377,18 @@ class Stereo:
 
     RESULT_KEYS = ("rectify_img1", "rectify_img2", "disparity", "rectify_depth", "unrectify_depth", "undistort_img1")
 
+    def get_depth_async(self, img1, img2, return_unrectify_depth=True, keys=None):
+        """``get_depth`` without its final wait (not in the reference, whose calls are synchronous): everything is
+        queued -- upload, kernels, the results' way back to page-locked host blocks -- and a ``PendingDepth`` is returned;
+        ``.result()`` waits for THIS call's copies only and hands over the same dict ``get_depth`` returns.  A caller
+        that keeps two or three calls in flight overlaps the ~1 ms a 1080p result dict spends on PCIe with the next
+        call's kernels: one pair per call then runs at the rate of the kernels alone (tools/gpu_numpy_latency.py)."""
+        return self._get_depth(img1, img2, return_unrectify_depth, False, keys, defer=True)
+
     def get_depth(self, img1, img2, return_unrectify_depth=True, return_distort_depth=False, keys=None):
+        return self._get_depth(img1, img2, return_unrectify_depth, return_distort_depth, keys, defer=False)
+
+    def _get_depth(self, img1, img2, return_unrectify_depth, return_distort_depth, keys, defer):
         """Return dict: rectify_img1, rectify_depth, disparity, rectify_img2 (+ unrectify_depth,
         undistort_img1). Depth unit is m; 0 = invalid.  ndarray inputs give ndarray results (each result starts
         its way to the host as soon as its kernel is queued, hostio.Sink); device tensors stay on the device.
@@ -431,6 +457,8 @@ class Stereo:
             unrect = self.unrectify_depth(rectify_depth)
             emit(unrectify_depth=unrect)
         emit(disparity=disparity, rectify_depth=rectify_depth)
+        if defer:
+            return PendingDepth(result, sink)
         if sink is not None:
             result.update(sink.collect())
             if isinstance(plugin, SemiGlobalBlockMatching):

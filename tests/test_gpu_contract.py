@@ -354,3 +354,27 @@ def test_get_depth_keys_returns_the_asked_entries_only():
     assert list(t) == ["unrectify_depth"] and np.array_equal(t["unrectify_depth"].cpu().numpy(), full["unrectify_depth"])
     with pytest.raises(ValueError):
         stereo.get_depth(img1, img2, keys=("depth",))
+
+
+def test_get_depth_async_returns_the_same_dicts_in_order():
+    """``get_depth_async`` (not in the reference) queues a call and returns; several calls in flight on different pairs,
+    results collected later and out of order, must each equal the synchronous call's dict."""
+    W, H = 320, 240
+    rec = synthetic.rig(W, H)
+    stereo = ca.Stereo.load(rec)
+    cfg = dict(max_size=W, minDisparity=0, numDisparities=64, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1,
+               uniquenessRatio=10, speckleWindowSize=50, speckleRange=2)
+    stereo.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=3.5)
+    pairs = [synthetic.render_plane_pair(rec, (0.2, 0.1, 1.0), 1.6 + 0.3 * i, seed=i)[:2] for i in range(4)]
+    want = [stereo.get_depth(a, b) for a, b in pairs]
+    pend = [stereo.get_depth_async(a, b) for a, b in pairs]
+    for i in (2, 0, 3, 1):
+        got = pend[i].result()
+        assert sorted(got) == sorted(want[i])
+        assert all(isinstance(got[k], np.ndarray) and np.array_equal(got[k], want[i][k]) for k in got), i
+    assert pend[1].result() is pend[1].result()
+    one = stereo.get_depth_async(*pairs[1], keys=("unrectify_depth",)).result()
+    assert list(one) == ["unrectify_depth"] and np.array_equal(one["unrectify_depth"], want[1]["unrectify_depth"])
+    t = stereo.get_depth_async(torch.from_numpy(pairs[0][0]).cuda(), torch.from_numpy(pairs[0][1]).cuda()).result()
+    assert np.array_equal(t["disparity"].cpu().numpy(), want[0]["disparity"])
+    stereo.stereo_matching.stereo_sgbm.status()

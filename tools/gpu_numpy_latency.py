@@ -25,6 +25,20 @@ for tag, W, H, D in (("1080p_d128", 1920, 1080, 128), ("vga_d64", 640, 480, 64))
         for _ in range(20): out = stereo.get_depth(i1, i2, keys=keys)
         res[tag + "_numpy_%s_ms" % name] = (time.perf_counter() - t0) / 20 * 1e3
         res[tag + "_%s_MB" % name] = sum(v.nbytes for v in out.values()) / 1e6
+    # one pair per call, but up to `depth` calls in flight (Stereo.get_depth_async): calls per second
+    import collections
+    for depth in (2, 3):
+        for name, keys in (("full_dict", None), ("unrectify_depth_only", ("unrectify_depth",))):
+            q = collections.deque()
+            n = 40
+            for k in range(n + 6):
+                if k == 6:
+                    while q: q.popleft().result()
+                    t0 = time.perf_counter()
+                q.append(stereo.get_depth_async(i1, i2, keys=keys))
+                if len(q) >= depth: out = q.popleft().result()
+            while q: out = q.popleft().result()
+            res[tag + "_async_%d_in_flight_%s_calls_per_s" % (depth, name)] = n / (time.perf_counter() - t0)
     t1, t2 = torch.from_numpy(i1).cuda(), torch.from_numpy(i2).cuda()
     for _ in range(3): stereo.get_depth(t1, t2)
     torch.cuda.synchronize(); t0 = time.perf_counter()
