@@ -189,6 +189,10 @@ class Stereo:
 
     # ---- record I/O --------------------------------------------------------------------------------
     def dump(self, path="", return_dict=False):
+        if getattr(self, "_bundle_only", False):
+            raise ValueError("this rig was built from a broadcast table bundle (Stereo.from_bundle): it holds neither the "
+                             "rig's R nor camera 2's intrinsics, so there is no record to dump -- dump the rig on the rank "
+                             "that loaded it")
         rec = {k: (v.tolist() if isinstance(v, np.ndarray) else v)
                for k, v in vars(self).items() if k in self.DUMP_ATTRS}
         rec.update(cam1=self.cam1.dump(return_dict=True), cam2=self.cam2.dump(return_dict=True))
@@ -465,7 +469,7 @@ class Stereo:
                 plugin.stereo_sgbm.status()  # collect() synchronised: surface device-side timeouts at no extra cost
         return result
 
-    def get_depth_batch(self, imgs1, imgs2, return_unrectify_depth=True):
+    def get_depth_batch(self, imgs1, imgs2, return_unrectify_depth=True, keys=None):
         """``get_depth`` for ``n`` pairs of the same rig at once: ``imgs1`` / ``imgs2`` are ``(n, h, w, 3)``
         uint8 (NumPy or torch CUDA), every value of the returned dict carries the leading ``n``.
 
@@ -473,9 +477,17 @@ class Stereo:
         throughput form of the same stages -- each kernel is launched once for the whole batch, which is
         what keeps small images (VGA) from being launch-bound.  Pair ``i`` of the result is bit-identical
         to ``get_depth(imgs1[i], imgs2[i])``.  Requires the SGBM plugin; a ``max_size`` below the rectified image
-        size downsizes the whole batch first, as the matcher does for one pair.
+        size downsizes the whole batch first, as the matcher does for one pair.  ``keys``: as in ``get_depth`` -- only
+        the asked entries are returned (and copied to the host for ndarray input; a batch of 64 1080p pairs is 3.8 GB).
         """
         assert hasattr(self, "stereo_matching"), "Please stereo.set_stereo_matching(stereo_matching)"
+        if keys is not None:
+            keys = (keys,) if isinstance(keys, str) else tuple(keys)
+            unknown = [k for k in keys if k not in self.RESULT_KEYS]
+            if unknown:
+                raise ValueError("get_depth_batch(keys=...): unknown result entries %s (known: %s)" % (unknown, list(self.RESULT_KEYS)))
+            return_unrectify_depth = "unrectify_depth" in keys or "undistort_img1" in keys
+        want = (lambda k: True) if keys is None else (lambda k: k in keys)
         i1, was_np = self._to_dev(imgs1)
         i2, _ = self._to_dev(imgs2)
         # (the two cameras of a rig may differ in resolution -- each is rectified through its own maps,
@@ -496,8 +508,12 @@ class Stereo:
         result = dict(rectify_img1=rectify_img1, rectify_depth=rectify_depth, disparity=disparity,
                       rectify_img2=rectify_img2)
         if return_unrectify_depth:
-            result.update(unrectify_depth=self.unrectify_depth(rectify_depth), undistort_img1=self.undistort_img(i1))
-        if was_np:
+            if want("unrectify_depth"):
+                result.update(unrectify_depth=self.unrectify_depth(rectify_depth))
+            if want("undistort_img1"):
+                result.update(undistort_img1=self.undistort_img(i1))
+        result = {k: v for k, v in result.items() if want(k)}
+        if was_np and result:
             result = dict(zip(result, hostio.to_host(*result.values())))
             sm.stereo_sgbm.status()  # to_host synchronised: surface device-side timeouts at no extra cost
         return result

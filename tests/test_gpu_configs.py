@@ -131,3 +131,5 @@ def test_rig_from_a_table_bundle_alone_equals_the_rig_from_the_record():
     assert (got["unrectify_depth"] > 0).mean() > 0.3
     gb = worker.get_depth_batch(np.stack([img1, img1]), np.stack([img2, img2]))
     assert all(np.array_equal(gb[k][1], want[k]) for k in want)
+    with pytest.raises(ValueError, match="table bundle"):
+        worker.dump()  # no R, no camera 2 intrinsics: nothing to write, and it says so

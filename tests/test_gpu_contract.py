@@ -354,6 +354,12 @@ def test_get_depth_keys_returns_the_asked_entries_only():
     assert list(t) == ["unrectify_depth"] and np.array_equal(t["unrectify_depth"].cpu().numpy(), full["unrectify_depth"])
     with pytest.raises(ValueError):
         stereo.get_depth(img1, img2, keys=("depth",))
+    # the batched form takes the same argument
+    gb = stereo.get_depth_batch(np.stack([img1, img1]), np.stack([img2, img2]), keys=("unrectify_depth", "disparity"))
+    assert sorted(gb) == ["disparity", "unrectify_depth"]
+    assert all(np.array_equal(gb[k][1], full[k]) for k in gb)
+    with pytest.raises(ValueError):
+        stereo.get_depth_batch(np.stack([img1]), np.stack([img2]), keys=("nope",))
 
 
 def test_get_depth_async_returns_the_same_dicts_in_order():
