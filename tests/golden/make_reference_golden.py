@@ -217,6 +217,12 @@ def run_case(cal, case, out):
     for k in ("R", "t", "R1", "R2", "K"):
         out["%s/%s" % (name, k)] = np.array(getattr(st, k), np.float64)
     out[name + "/xy"] = np.array(st.xy, np.int64)
+    # -- the record the reference writes back (Stereo.dump / Cam.dump, stereo_camera.py:246-262, camera.py:407-422), and
+    #    what its own load makes of that YAML text (:264-297)
+    import json
+    out[name + "/dump_json"] = np.array(json.dumps(st.dump(return_dict=True), sort_keys=True))
+    again = cal.Stereo(**case.get("stereo", {})).load(st.dump())
+    out[name + "/yaml_roundtrip"] = np.concatenate([np.asarray(getattr(again, k), np.float64).reshape(-1) for k in ("R", "t", "R1", "R2", "K")])
     out[name + "/scalars"] = np.array([st.min_disparity, float(st.translation_rectify_img), st.max_depth, st.baseline,
                                        st.get_max_depth()], np.float64)
     out[name + "/mask_bits"] = np.packbits(st.rectify_valid_mask1)

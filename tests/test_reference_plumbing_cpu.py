@@ -65,6 +65,22 @@ def test_oracle_pipeline_reproduces_the_references_get_depth(fx, oracle, name):
     assert not inexact, ("same within 1e-4 m but not the reference's float64 bits", inexact)
 
 
+@pytest.mark.parametrize("name", [c["name"] for c in rc.CASES])
+def test_dump_and_yaml_round_trip_equal_the_references(fx, name):
+    """``Stereo.dump(return_dict=True)`` writes the record the reference writes (same keys, same numbers: R, t, per camera
+    fx / fy / cx / cy, D, xy, name), and loading the YAML text of a dump arrives where the reference's own load of ITS
+    text arrives (stereo_camera.py:246-297, camera.py:407-448)."""
+    import json
+    case = rc.CASE_BY_NAME[name]
+    st = _stereo(fx, case)
+    assert json.dumps(st.dump(return_dict=True), sort_keys=True) == str(fx[name + "/dump_json"])
+    text = st.dump()
+    assert "\n" in text and "_calibrating_version" in text
+    again = ca.Stereo(**case.get("stereo", {})).load(text)
+    got = np.concatenate([np.asarray(getattr(again, k), np.float64).reshape(-1) for k in ("R", "t", "R1", "R2", "K")])
+    assert np.array_equal(got, fx[name + "/yaml_roundtrip"])
+
+
 def test_fixture_is_complete(fx):
     assert str(fx["reference_version"]) == "0.8.7"
     for c in rc.CASES:
