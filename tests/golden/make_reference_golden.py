@@ -219,6 +219,8 @@ def run_case(cal, case, out):
     out[name + "/xy"] = np.array(st.xy, np.int64)
     # -- the record the reference writes back (Stereo.dump / Cam.dump, stereo_camera.py:246-262, camera.py:407-422), and
     #    what its own load makes of that YAML text (:264-297)
+    out[name + "/T"] = np.asarray(st.T, np.float64)                       # utils.R_t_to_T: R through float32 (Q9)
+    out[name + "/depth_to_disparity"] = np.asarray(st.depth_to_disparity(np.float64([0.5, 1.0, 2.5, 80.0])), np.float64)
     import json
     out[name + "/dump_json"] = np.array(json.dumps(st.dump(return_dict=True), sort_keys=True))
     again = cal.Stereo(**case.get("stereo", {})).load(st.dump())

@@ -74,6 +74,9 @@ def test_dump_and_yaml_round_trip_equal_the_references(fx, name):
     case = rc.CASE_BY_NAME[name]
     st = _stereo(fx, case)
     assert json.dumps(st.dump(return_dict=True), sort_keys=True) == str(fx[name + "/dump_json"])
+    assert np.array_equal(np.asarray(st.T, np.float64), fx[name + "/T"])  # R rounded through float32
+    assert np.array_equal(st.depth_to_disparity(np.float64([0.5, 1.0, 2.5, 80.0])), fx[name + "/depth_to_disparity"])
+    assert np.array_equal(st.D, np.zeros((1, 5)))
     text = st.dump()
     assert "\n" in text and "_calibrating_version" in text
     again = ca.Stereo(**case.get("stereo", {})).load(text)
