@@ -390,9 +390,6 @@ class Stereo:
         return self._get_depth(img1, img2, return_unrectify_depth, False, keys, defer=True)
 
     def get_depth(self, img1, img2, return_unrectify_depth=True, return_distort_depth=False, keys=None):
-        return self._get_depth(img1, img2, return_unrectify_depth, return_distort_depth, keys, defer=False)
-
-    def _get_depth(self, img1, img2, return_unrectify_depth, return_distort_depth, keys, defer):
         """Return dict: rectify_img1, rectify_depth, disparity, rectify_img2 (+ unrectify_depth,
         undistort_img1). Depth unit is m; 0 = invalid.  ndarray inputs give ndarray results (each result starts
         its way to the host as soon as its kernel is queued, hostio.Sink); device tensors stay on the device.
@@ -401,6 +398,10 @@ class Stereo:
         dict of a 1080p pair is ~60 MB -- two float64 depth maps among them -- and its way back over PCIe costs as much
         as a third of the kernels; entries that are not asked for are neither copied nor, where nothing else needs
         them (undistort_img1, unrectify_depth), computed.  ``None`` = the reference's dict."""
+        return self._get_depth(img1, img2, return_unrectify_depth, return_distort_depth, keys, defer=False)
+
+    def _get_depth(self, img1, img2, return_unrectify_depth, return_distort_depth, keys, defer):
+        """The body of get_depth / get_depth_async (``defer``: hand back a PendingDepth instead of waiting)."""
         import torch
         assert hasattr(self, "stereo_matching"), "Please stereo.set_stereo_matching(stereo_matching)"
         if return_distort_depth:
