@@ -41,7 +41,9 @@ int camd_device_ok(void);
 
 /* A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): bit i of cu_mask[i / 32]
  * enables CU i in the driver's enumeration, which walks the XCDs first -- bit 0 = XCD 0's first CU, bit 1 = XCD 1's,
- * ... -- so the first N bits are N / 8 CUs of every XCD.  For spatial partitioning of concurrent work (one partition
+ * ... -- so the first N bits are N / 8 CUs of every XCD (measured: tools/gpu_cumask_probe.py).  An XCD whose share of
+ * the mask is empty is left unrestricted, not disabled, and workgroups are dealt to the XCDs in equal shares: give
+ * every XCD the same number of CUs, a multiple of its four shader engines (N a multiple of 32).  For spatial partitioning of concurrent work (one partition
  * for a VALU-bound kernel, the rest for an HBM-bound one).  The reference has no counterpart (single-threaded host
  * code); nothing on the default path creates such a stream.  *stream is a hipStream_t. */
 int camd_stream_create_cu_mask(const uint32_t* cu_mask, int nwords, void** stream);
