@@ -9,8 +9,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (bench.py --lib points this at an experimental build of the same ABI before the first call: A/B kernel variants)
-LIB_PATH = os.path.join(_HERE, "lib", "libcalibrating_amd.so")
+# (bench.py --lib, or CAMD_LIB in the environment of a test / measurement run, points this at an experimental build of
+# the same ABI before the first call: A/B of kernel variants built by tools/build_dbg.sh.  Still a HIP library: there
+# is no CPU fallback either way)
+LIB_PATH = os.environ.get("CAMD_LIB") or os.path.join(_HERE, "lib", "libcalibrating_amd.so")
 _lib = None
 
 c_void_p, c_int, c_size_t, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double

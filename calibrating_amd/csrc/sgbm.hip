@@ -1488,9 +1488,13 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         // waves per workgroup: one per 8 disparities, at least 4 (the staging needs up to 3 waves of lanes), at most
         // 8 for RGB (three 8-wave workgroups share a CU at 74 VGPRs: 17.5 instead of 20.2 ms per 64 pairs; a 16-wave
         // workgroup would have a CU to itself) and 16 for gray (fewer registers, and the staging per cell halves)
-        const int maxw = g.cn == 3 ? CAMD_COST_MAX_WAVES_RGB : CAMD_COST_MAX_WAVES_GRAY;
-        const int nw = g.Dp / COST_DL < 4 ? 4 : (g.Dp / COST_DL < maxw ? g.Dp / COST_DL : maxw);
-        const int ndblk = div_up(g.Dp, nw * COST_DL);                   // disparity blocks of <= 128
+        // 16 disparities per lane (CAMD_COST_DL16): a workgroup of 8 waves then covers 128 disparities, so the BT operands
+        // of a strip are staged once instead of once per 64-disparity block, at K x 8 ring registers per lane
+        const bool dl16 = CAMD_COST_DL16 && K <= 5 && g.Dp >= 64 && (g.cn == 3 || CAMD_COST_DL16 > 1);
+        const int dl = dl16 ? 16 : COST_DL;
+        const int maxw = g.cn == 3 || dl16 ? CAMD_COST_MAX_WAVES_RGB : CAMD_COST_MAX_WAVES_GRAY;
+        const int nw = g.Dp / dl < 4 ? 4 : (g.Dp / dl < maxw ? g.Dp / dl : maxw);
+        const int ndblk = div_up(g.Dp, nw * dl);                        // disparity blocks of <= 128
         const int nstrips = div_up(g.W1, 64 - (K - 1));
         // row chunks: enough workgroups for ~32 rounds over the chip.  The saturating recurrence must start at row 0
         // (one chunk: few workgroups, a long walk) -- but it only differs from the wrapping one on images that drive a
@@ -1521,22 +1525,26 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
             const int rb = div_up(h->ga.H, nchunks);  // rows per chunk, in the longest range
             nchunks = div_up(h->ga.H, rb);
             dim3 grid(nstrips, nchunks * ndblk, vbatch), block(64 * nw);
-            const size_t lds = cost_lds_bytes(g.cn, nw);
-#define CAMD_COST(CNN, KK, SS)                                                                                       \
-    hipLaunchKernelGGL((k_cost<CNN, KK, SS>), grid, block, lds, st, left, right, pitch, image_stride, h->C, g, rb, \
+            const size_t lds = cost_lds_bytes(g.cn, nw, dl);
+#define CAMD_COST_DLX(CNN, KK, SS, DLL)                                                                                   \
+    hipLaunchKernelGGL((k_cost<CNN, KK, SS, DLL>), grid, block, lds, st, left, right, pitch, image_stride, h->C, g, rb, \
                        nchunks, h->vol_elems, h->cr, ovf, thresh, h->cost_neg)
+#define CAMD_COST(CNN, KK, SS) CAMD_COST_DLX(CNN, KK, SS, COST_DL)
+#define CAMD_COST16(CNN, KK, SS) do { if (dl16) CAMD_COST_DLX(CNN, KK, SS, 16); else CAMD_COST_DLX(CNN, KK, SS, COST_DL); } while (0)
 #define CAMD_COST_K(CNN)                                                                         \
     switch (K) {                                                                                 \
-        case 1: CAMD_COST(CNN, 1, false); break;                                                 \
-        case 3: CAMD_COST(CNN, 3, false); break;                                                 \
-        case 5: if (sat_kernel) CAMD_COST(CNN, 5, true); else CAMD_COST(CNN, 5, false); break;   \
+        case 1: CAMD_COST16(CNN, 1, false); break;                                               \
+        case 3: CAMD_COST16(CNN, 3, false); break;                                               \
+        case 5: if (sat_kernel) CAMD_COST16(CNN, 5, true); else CAMD_COST16(CNN, 5, false); break; \
         case 7: if (sat_kernel) CAMD_COST(CNN, 7, true); else CAMD_COST(CNN, 7, false); break;   \
         case 9: if (sat_kernel) CAMD_COST(CNN, 9, true); else CAMD_COST(CNN, 9, false); break;   \
         default: if (sat_kernel) CAMD_COST(CNN, 11, true); else CAMD_COST(CNN, 11, false);       \
     }
             if (g.cn == 1) { CAMD_COST_K(1) } else { CAMD_COST_K(3) }
 #undef CAMD_COST_K
+#undef CAMD_COST16
 #undef CAMD_COST
+#undef CAMD_COST_DLX
         };
         if (may_overflow) CAMD_HIP(hipMemsetAsync(h->cost_neg, 0, (size_t)vbatch * 4, st));
         if (two_stage) {

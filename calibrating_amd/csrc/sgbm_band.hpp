@@ -35,12 +35,24 @@
 namespace camd {
 
 // 7 compute waves + 1 helper wave = 8 waves per workgroup: two workgroups fill a CU's 16 wave slots at
-// <= 128 VGPRs (nine waves would leave room for only one)
+// <= 128 VGPRs (nine waves would leave room for only one).
+//   CAMD_BAND_MERGED 1 (measurement build; rounds 3 and 6): all 8 waves compute (bands of 8 * 64 / LANES rows) and wave
+//       CAMD_BAND_DUTY_WAVE runs the helper's few instructions every CPB steps on the side, so that every SIMD carries
+//       four compute waves instead of 4, 4, 3, 3.  Bit-exact, and no faster: first pass 15.07 against 15.05 ms per 64
+//       pairs, MODE_SGBM last pass 11.4 / 11.6, MODE_HH last pass 23.0 against 19.1 (122 / 128 VGPRs, the latter with
+//       100 bytes of scratch) -- profiles/r06_band_ab.txt.  The pass is not bound by its busiest SIMDs: half the
+//       arithmetic (MODE_HH4's two directions) takes 12.4 ms, no S stores 12.9, both 8.5 (profiles/r06_band_probe.txt).
+#ifndef CAMD_BAND_MERGED
+#define CAMD_BAND_MERGED 0
+#endif
 #ifndef CAMD_BAND_COMPUTE_WAVES
-#define CAMD_BAND_COMPUTE_WAVES 7
+#define CAMD_BAND_COMPUTE_WAVES (CAMD_BAND_MERGED ? 8 : 7)
 #endif
 #ifndef CAMD_BAND_HELPER_WAVE
-#define CAMD_BAND_HELPER_WAVE CAMD_BAND_COMPUTE_WAVES    // which wave of the workgroup is the helper (default: the last)
+#define CAMD_BAND_HELPER_WAVE CAMD_BAND_COMPUTE_WAVES    // !MERGED: which wave of the workgroup is the helper (default: the last)
+#endif
+#ifndef CAMD_BAND_DUTY_WAVE
+#define CAMD_BAND_DUTY_WAVE 0                            // MERGED: the compute wave that also feeds the edge ring
 #endif
 #ifndef CAMD_BAND_MIN_WAVES
 #define CAMD_BAND_MIN_WAVES 4                            // occupancy target (waves per SIMD) of the D <= 128 instantiations
@@ -54,7 +66,7 @@ namespace camd {
 #define CAMD_BAND_ROW_MIN_WAVES CAMD_BAND_MIN_WAVES      // occupancy target of the row-parallel pass (it needs 66 VGPRs)
 #endif
 static constexpr int BAND_THREADS = 64 * CAMD_BAND_COMPUTE_WAVES;  // compute threads
-static constexpr int BAND_BLOCK = BAND_THREADS + 64;     // + one helper wave
+static constexpr int BAND_BLOCK = BAND_THREADS + (CAMD_BAND_MERGED ? 0 : 64);  // (+ one helper wave)
 static constexpr int BAND_HELPER_WAVE = CAMD_BAND_HELPER_WAVE;
 static constexpr int BAND_RING = 4;                      // C/S prefetch ring (xi .. xi+3)
 #ifndef BAND_RING_ROWS
@@ -268,6 +280,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
 {
     constexpr int NQ = (NR + 3) / 4;  // 16-byte LDS slots / u64 edge-record pairs per lane and vector
     constexpr int NTH = (!FULL && CAMD_BAND_ROW_ALL_WAVES) ? BAND_BLOCK : BAND_THREADS;  // compute threads of a workgroup
+    static_assert(!CAMD_BAND_MERGED || BAND_BLOCK == BAND_THREADS, "merged helper duty: every wave computes");
     constexpr int R = NTH / LANES;
     constexpr int EVEC = 6 * NQ;     // u64 per lane per column: V (2NQ), Dg (2NQ), A (2NQ)
     constexpr int CPB = 64 / LANES;  // columns the helper wave fetches per batch
@@ -298,9 +311,9 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
     // compute thread index).  Which wave helps decides which SIMD carries one compute wave less (see
     // tools/microtests/wave_simd_placement.hip)
     const int wv = threadIdx.x >> 6;
-    const bool helper = (FULL || !CAMD_BAND_ROW_ALL_WAVES) && wv == BAND_HELPER_WAVE;  // wave-uniform
+    const bool helper = !CAMD_BAND_MERGED && (FULL || !CAMD_BAND_ROW_ALL_WAVES) && wv == BAND_HELPER_WAVE;  // wave-uniform
     if (!FULL && helper) return;
-    const int ctid = (!FULL && CAMD_BAND_ROW_ALL_WAVES) ? (int)threadIdx.x
+    const int ctid = (CAMD_BAND_MERGED || (!FULL && CAMD_BAND_ROW_ALL_WAVES)) ? (int)threadIdx.x
                      : helper ? (int)(threadIdx.x & 63) : (((wv > BAND_HELPER_WAVE ? wv - 1 : wv) << 6) | (int)(threadIdx.x & 63));
     const int grp = ctid / LANES, li = ctid % LANES;
     const int W1 = g.W1, H = g.H;
@@ -315,6 +328,8 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
     const int glast = min(R, H - band * R) - 1;
     const bool has_prev = FULL && band > 0, has_next = FULL && band + 1 < a.nbands;
     const bool producer = !helper && has_next && grp == glast;
+    // the wave that keeps the edge ring filled: the helper wave, or (MERGED) one compute wave on the side
+    const bool hduty = FULL && has_prev && (CAMD_BAND_MERGED ? __builtin_amdgcn_readfirstlane(wv) == CAMD_BAND_DUTY_WAVE : helper);
 
     const uint32_t P1pk = dup16((uint32_t)g.P1), P2pk = dup16((uint32_t)g.P2);
     uint32_t keep[NR], sent[NR], dpk[NR];
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
         if (hl % LANES == 0)
             edl[slot][hl / LANES] = make_uint4((uint32_t)pdl[0], (uint32_t)(pdl[0] >> 32), (uint32_t)pdl[1], 0u);
     };
-    if (FULL && helper && has_prev) {
+    if (hduty) {
         wait_cols(min(CPB, W1));
         fetch_batch(0);
         park_batch(0);
@@ -454,20 +469,22 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
 
     const int nsteps = (W1 + SK * glast + RING - 1) / RING * RING;
     uint32_t cap_key = WTA_NONE, cap_nb = 0;  // FINAL: the pixel this lane finishes at the next flush
+    // every CPB steps: batch t / CPB + 1 (fetched CPB steps ago) goes into the LDS ring, the batch after it is requested
+    auto duty_step = [&](int t) {
+        const int b = t / CPB + 1;
+        if (b * CPB < W1) park_batch(b);
+        const int bn = b + 1;
+        if (bn * CPB < W1) {
+            wait_cols(min((bn + 1) * CPB, W1));
+            fetch_batch(bn);
+        }
+    };
     if (FULL && helper) {
         // The helper runs its own loop with the same number of barriers: keeping the two roles in separate
         // loops leaves the compute loop free of control flow around its loads, which is what lets the
         // compiler count them (s_waitcnt vmcnt(N), N > 0) instead of draining the prefetch ring every step.
         for (int t = 0; t < nsteps; t++) {
-            if (has_prev && (t % CPB) == 0) {
-                const int b = t / CPB + 1;
-                if (b * CPB < W1) park_batch(b);
-                const int bn = b + 1;
-                if (bn * CPB < W1) {
-                    wait_cols(min((bn + 1) * CPB, W1));
-                    fetch_batch(bn);
-                }
-            }
+            if (has_prev && (t % CPB) == 0) duty_step(t);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef CAMD_BAND_DBG_NOBARRIER
             __builtin_amdgcn_s_barrier();
@@ -481,6 +498,10 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
             const int t = t0 + u;
             const int xi = t - SK * grp;
             const bool act = rvalid && xi >= 0 && xi < W1;
+            if (CAMD_BAND_MERGED && FULL) {
+                // (wave-uniform; with CPB == RING a compile-time position in the unrolled body)
+                if ((CPB == RING ? u == 0 : (t % CPB) == 0) && hduty) duty_step(t);
+            }
             {
                 constexpr int UP = (RING - 1);
                 const int xp = min(max(xi + UP, 0), W1 - 1);
@@ -544,9 +565,16 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
                         for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], LAo[k]);
                     }
                 }
+#if defined(CAMD_BAND_DBG_NOSTORE) && !defined(CAMD_MEASUREMENT_BUILD)
+#error "CAMD_BAND_DBG_NOSTORE produces wrong results: measurement builds only (define CAMD_MEASUREMENT_BUILD too)"
+#endif
+#ifdef CAMD_BAND_DBG_NOSTORE  // (measurement only: the pass without its V of stores; S must still look used)
+                if (s[0] == 0x12345678u) st_regs<NR>(Srow + cell_off(xi), s);
+#else
                 if (MODE != 2 || a.write_S) {
                     st_regs<NR>(Srow + cell_off(xi), s);
                 }
+#endif
                 if (MODE == 2) band_wta_step<LANES, NR, TIE8, NTH>(s, dpk, wS, g, ctid, grp, li, t, true, cap_key, cap_nb);
             }
             if (MODE == 2 && ((t & (LANES - 1)) == LANES - 1 || t == nsteps - 1)) {

@@ -33,7 +33,7 @@
 
 namespace camd {
 
-static constexpr int COST_DL = 8;  // disparities per lane
+static constexpr int COST_DL = 8;  // disparities per lane (the DL = 16 instantiations: two such octets, see k_cost)
 // tunables (measured on MI355X)
 #ifndef CAMD_COST_MAX_WAVES_RGB
 #define CAMD_COST_MAX_WAVES_RGB 8    // waves per workgroup (x 8 disparities each)
@@ -43,6 +43,27 @@ static constexpr int COST_DL = 8;  // disparities per lane
 #endif
 #ifndef CAMD_COST_MIN_WAVES
 #define CAMD_COST_MIN_WAVES 6        // occupancy target (waves per SIMD) the register allocator works to
+#endif
+#ifndef CAMD_COST_MIN_WAVES_DL16
+#define CAMD_COST_MIN_WAVES_DL16 4   // ... of the 16-disparities-per-lane form (K rows x 8 ring registers)
+#endif
+// The per-cell tail of the BT cost (sum over the colour planes with the raw planes >> 2, then two cells per register):
+//   0  round 2-5: v_pk_lshrrev_b16 + v_dot2_u32_u16 per channel and cell, v_lshl_or + v_and per pair of cells --
+//      all of them in the class that issues at ~0.9 per cycle and CU (tools/microtests/valu_rate.hip)
+//   1  floor(x / 4) summed over the channels = (sum of (x & ~3)) >> 2: the mask rides in the v_bitop3_b32 that ORs the
+//      two saturating differences anyway, the channels are summed with plain v_add_u32 (no half can carry:
+//      3 * 255 < 2^16), and the gradient / raw halves of two cells are regrouped by two v_perm_b32 so that ONE plain
+//      shift + add finishes both cells.  Per RGB cell: 7 "slow-class" instructions -> 1, + 3.5 plain ones.
+#ifndef CAMD_COST_TAIL
+#define CAMD_COST_TAIL 1
+#endif
+// the staging arithmetic: 0 = round 2-5 form, 1 = round 6 form (see stage_entries)
+#ifndef CAMD_COST_STAGE
+#define CAMD_COST_STAGE 1
+#endif
+// 1: RGB at blockSize <= 5 runs 16 disparities per lane (sgbm.hip: the launch); 2: gray too; 0: 8 everywhere
+#ifndef CAMD_COST_DL16
+#define CAMD_COST_DL16 0
 #endif
 
 // n applications of the one-lane wave shift (lane i <- lane i-1, lane 0 <- 0)
@@ -115,9 +136,9 @@ struct CostRanges {
     int start[4], rows[4];
 };
 
-static inline size_t cost_lds_bytes(int cn, int nwaves)
+static inline size_t cost_lds_bytes(int cn, int nwaves, int dl = COST_DL)
 {
-    const int es = cn == 1 ? 4 : 12, dw = nwaves * COST_DL;
+    const int es = cn == 1 ? 4 : 12, dw = nwaves * dl;
     const int nr = 64 + dw - 1, nl = 64;
     return (size_t)2 * (nr + nl) * es * 4;
 }
@@ -130,15 +151,17 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // The register ring of the vertical box sum holds K rows of 4 registers: from blockSize 9 on the kernel does not fit the
 // 80 registers of six waves per SIMD (blockSize 11 RGB, the reference's default: 40 spilled, 10.5 ms per 64 pairs of
 // 1000 x 562, D = 218); allowed 96 / 128 it runs without scratch traffic on fewer waves: 9.7 / 9.6 ms.
-constexpr int cost_min_waves(int K) { return K >= 11 ? 4 : (K >= 9 ? 5 : CAMD_COST_MIN_WAVES); }
+constexpr int cost_min_waves(int K, int DL = COST_DL)
+{
+    return DL > 8 ? CAMD_COST_MIN_WAVES_DL16 : (K >= 11 ? 4 : (K >= 9 ? 5 : CAMD_COST_MIN_WAVES));
+}
 
-template <int CN, int K, bool SAT>
-__global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+template <int CN, int K, bool SAT, int DL = COST_DL>
+__global__ __launch_bounds__(1024, cost_min_waves(K, DL)) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
                                                Geom g, int rb, int nchunks, size_t vol_stride, CostRanges cr,
                                                uint32_t* __restrict__ ovf, int ovf_thresh, uint32_t* __restrict__ neg)
 {
-    constexpr int DL = COST_DL;
     constexpr int ES = CN == 1 ? 4 : 12;  // dwords per staged entry: (p, lo, hi) per channel, padded to 16 bytes
     constexpr int EV = ES / 4;
     constexpr int NP = DL / 2;            // packed cost registers per lane
@@ -237,36 +260,75 @@ __global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t*
             }
         }
     };
+    // The entry arithmetic, round 6 form (CAMD_COST_STAGE 1): everything that can be a plain 32-bit operation is one
+    // (tools/microtests/valu_rate.hip: they issue at ~1.55 per cycle and CU, the packed / DPP / three-operand forms at
+    // ~0.9).  Vertical Sobel part on the even and the odd bytes of the pixel dwords, two channels per register:
+    //     sE = (s0 | s2 << 16),  sO = (s1 | junk << 16),   s = I(y-1) + 2 I(y) + I(y+1) <= 1020
+    // gradient s(x+1) - s(x-1) with a bias of 1024 per half so that the plain subtraction cannot borrow, clipped by a
+    // packed max / min against (1024 -+ ftz), re-based by a plain subtraction; one v_perm_b32 per channel pairs it with
+    // the raw byte.  The half-pixel interval uses  min(u, (u+l)/2, (u+r)/2) = (u + min(u, l, r)) / 2  (t -> (u+t)/2 is
+    // monotone; likewise max), the halving sum of two 8-bit values in 16-bit fields being one v_lerp_u8.
+    // Per staged RGB column 35 of the slower class + 20 plain instead of 55 + 11 (round 2-5 form: CAMD_COST_STAGE 0).
+    const uint32_t st_keep = st_inside ? 0xffffffffu : 0u, st_fill = st_inside ? 0u : ftz2;
+    const uint32_t clip_lo = dup16(1024u - (uint32_t)ftz), clip_hi = dup16(1024u + (uint32_t)ftz);
     auto stage_entries = [&](int buf) {
         if (stager) {  // wave-uniform up to the last staging wave
             uint32_t u[CN], lo[CN], hi[CN];
             const uint32_t a = rowA >> st_shift, b = rowB >> st_shift, c = rowC >> st_shift;
+            if (CAMD_COST_STAGE == 0) {
 #pragma unroll
-            for (int ch = 0; ch < CN; ch++) {
-                // vertical part of the x-Sobel: s = I(y-1) + 2 I(y) + I(y+1) -- the three rows of this channel
-                // gathered into one dword, then one dot product with (1, 2, 1)
-                const uint32_t t = __builtin_amdgcn_perm(b, a, 0x0c0c0400u + 0x00000101u * ch);      // (a.ch, b.ch, 0, 0)
-                const uint32_t t3 = __builtin_amdgcn_perm(c, t, 0x0c040100u + 0x00010000u * ch);     // (a.ch, b.ch, c.ch, 0)
-                const uint32_t sv = __builtin_amdgcn_udot4(t3, 0x00010201u, 0u, false);
-                // gradient = s(x+1) - s(x-1), clipped to [-ftz, ftz], + ftz;  p = gradient | raw << 16
-                // (the subtrahend passes through an empty asm so that the DPP move is NOT folded into the subtraction:
-                // the folded form, v_subrev_u32_dpp, measured wrong on gfx950 -- it returned shr(src1) - src0)
-                uint32_t sl = dpp_perm<DPP_WAVE_SHR1>(sv);
-                asm volatile("" : "+v"(sl));
-                const int gq = (int)dpp_perm<DPP_WAVE_SHL1>(sv) - (int)sl;
-                const uint32_t gc = (uint32_t)(min(max(gq, -ftz), ftz) + ftz);
-                const uint32_t raw = (b >> (8 * ch)) & 0xffu;
-                u[ch] = st_inside ? (gc | (raw << 16)) : ftz2;
-            }
+                for (int ch = 0; ch < CN; ch++) {
+                    // vertical part of the x-Sobel: s = I(y-1) + 2 I(y) + I(y+1) -- the three rows of this channel
+                    // gathered into one dword, then one dot product with (1, 2, 1)
+                    const uint32_t t = __builtin_amdgcn_perm(b, a, 0x0c0c0400u + 0x00000101u * ch);      // (a.ch, b.ch, 0, 0)
+                    const uint32_t t3 = __builtin_amdgcn_perm(c, t, 0x0c040100u + 0x00010000u * ch);     // (a.ch, b.ch, c.ch, 0)
+                    const uint32_t sv = __builtin_amdgcn_udot4(t3, 0x00010201u, 0u, false);
+                    // gradient = s(x+1) - s(x-1), clipped to [-ftz, ftz], + ftz;  p = gradient | raw << 16
+                    // (the subtrahend passes through an empty asm so that the DPP move is NOT folded into the subtraction:
+                    // the folded form, v_subrev_u32_dpp, measured wrong on gfx950 -- it returned shr(src1) - src0)
+                    uint32_t sl = dpp_perm<DPP_WAVE_SHR1>(sv);
+                    asm volatile("" : "+v"(sl));
+                    const int gq = (int)dpp_perm<DPP_WAVE_SHL1>(sv) - (int)sl;
+                    const uint32_t gc = (uint32_t)(min(max(gq, -ftz), ftz) + ftz);
+                    const uint32_t raw = (b >> (8 * ch)) & 0xffu;
+                    u[ch] = st_inside ? (gc | (raw << 16)) : ftz2;
+                }
 #pragma unroll
-            for (int ch = 0; ch < CN; ch++) {
-                // half-pixel interval: columns outside the image carry ftz2 like the border columns, so the
-                // "no neighbour at the image edge" rule (use p itself) needs no special case
-                const uint32_t l = dpp_perm<DPP_WAVE_SHR1>(u[ch]), r = dpp_perm<DPP_WAVE_SHL1>(u[ch]);
-                const uint32_t ul = pk_lshr_u16(pk_add_u16(u[ch], l), 0x00010001u);
-                const uint32_t ur = pk_lshr_u16(pk_add_u16(u[ch], r), 0x00010001u);
-                lo[ch] = pk_min_u16(pk_min_u16(ul, ur), u[ch]);
-                hi[ch] = pk_max_u16(pk_max_u16(ul, ur), u[ch]);
+                for (int ch = 0; ch < CN; ch++) {
+                    // half-pixel interval: columns outside the image carry ftz2 like the border columns, so the
+                    // "no neighbour at the image edge" rule (use p itself) needs no special case
+                    const uint32_t l = dpp_perm<DPP_WAVE_SHR1>(u[ch]), r = dpp_perm<DPP_WAVE_SHL1>(u[ch]);
+                    const uint32_t ul = pk_lshr_u16(pk_add_u16(u[ch], l), 0x00010001u);
+                    const uint32_t ur = pk_lshr_u16(pk_add_u16(u[ch], r), 0x00010001u);
+                    lo[ch] = pk_min_u16(pk_min_u16(ul, ur), u[ch]);
+                    hi[ch] = pk_max_u16(pk_max_u16(ul, ur), u[ch]);
+                }
+            } else {
+                uint32_t vc[2];  // clipped gradients + ftz: (ch0 | ch2 << 16), (ch1 | junk << 16)
+#pragma unroll
+                for (int eo = 0; eo < (CN == 1 ? 1 : 2); eo++) {
+                    const uint32_t M = CN == 1 ? 0xffu : 0x00ff00ffu;
+                    const uint32_t ea = (eo ? a >> 8 : a) & M, eb = (eo ? b >> 8 : b) & M, ec = (eo ? c >> 8 : c) & M;
+                    const uint32_t sv = ea + ec + eb + eb;
+                    // (the subtrahend passes through an empty asm so that its DPP move is NOT folded into the
+                    // subtraction: the folded form, v_subrev_u32_dpp, measured wrong on gfx950)
+                    uint32_t sl = dpp_perm<DPP_WAVE_SHR1>(sv);
+                    asm volatile("" : "+v"(sl));
+                    const uint32_t gq = dpp_perm<DPP_WAVE_SHL1>(sv) - sl + 0x04000400u;  // 1024 + gradient per half
+                    vc[eo] = pk_min_u16(pk_max_u16(gq, clip_lo), clip_hi) - clip_lo;
+                }
+#pragma unroll
+                for (int ch = 0; ch < CN; ch++) {
+                    // (gradient of the channel | its raw byte << 16); columns 0 and W-1 (and beyond) hold tab[0]
+                    const uint32_t sel = ch == 0 ? 0x0c040100u : (ch == 1 ? 0x0c050100u : 0x0c060302u);
+                    u[ch] = (__builtin_amdgcn_perm(b, vc[ch & 1], sel) & st_keep) | st_fill;
+                }
+#pragma unroll
+                for (int ch = 0; ch < CN; ch++) {
+                    const uint32_t l = dpp_perm<DPP_WAVE_SHR1>(u[ch]), r = dpp_perm<DPP_WAVE_SHL1>(u[ch]);
+                    lo[ch] = __builtin_amdgcn_lerp(u[ch], pk_min_u16(pk_min_u16(l, r), u[ch]), 0u);
+                    hi[ch] = __builtin_amdgcn_lerp(u[ch], pk_max_u16(pk_max_u16(l, r), u[ch]), 0u);
+                }
             }
             if (st_store) {
                 u32x4_t* d4 = reinterpret_cast<u32x4_t*>(st_dst + buf * esz);
@@ -288,10 +350,12 @@ __global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t*
 
     // ---- per-lane constants -----------------------------------------------------------------------------------
     const int d0 = db + w * DL;                               // first disparity index of this wave
+    const int d0u = db + __builtin_amdgcn_readfirstlane(w) * DL;  // (the same, known to be wave-uniform: SGPR operands)
     uint32_t keep[NP];                                        // padded disparities d >= D carry pix = 0 (C = P2)
 #pragma unroll
     for (int k = 0; k < NP; k++)
-        keep[k] = (d0 + 2 * k < g.D ? 0xffffu : 0u) | (d0 + 2 * k + 1 < g.D ? 0xffff0000u : 0u);
+        keep[k] = (d0u + 2 * k < g.D ? 0xffffu : 0u) | (d0u + 2 * k + 1 < g.D ? 0xffff0000u : 0u);
+    const uint32_t rawmask = 0xfffcffffu;                     // (gradient | raw << 16): raw rounded down to 4 n
     int eoff_l = NRmax * EV + (cx - cmin) * EV;                                    // uint4 index of the left entry
     int eoff_r = ((cx - cmin) + DW - 1 - w * DL - (DL - 1)) * EV;                  // right entry of cell DL-1
     // opaque to the optimiser: the per-cell entries are then reached with non-negative immediate offsets from this
@@ -354,21 +418,40 @@ __global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t*
                     for (int c = 0; c < CN; c++) {
                         // c0 = max(0, u - v1, v0 - u), c1 = max(0, v - u1, u0 - v): at most one term of each pair
                         // is non-zero, so OR of the saturating differences is their max
-                        const uint32_t a = pk_subsat_u16(U[c], V1[c]) | pk_subsat_u16(V0[c], U[c]);
-                        const uint32_t b = pk_subsat_u16(V[c], U1[c]) | pk_subsat_u16(U0[c], V[c]);
-                        uint32_t m = pk_min_u16(a, b);
-                        m = pk_lshr_u16(m, 0x00020000u);  // raw plane: cost >> 2
-                        a32 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, m),
-                                                     __builtin_bit_cast(u16x2_t, 0x00010001u), a32, false);
+                        if (CAMD_COST_TAIL == 0) {
+                            const uint32_t a = pk_subsat_u16(U[c], V1[c]) | pk_subsat_u16(V0[c], U[c]);
+                            const uint32_t b = pk_subsat_u16(V[c], U1[c]) | pk_subsat_u16(U0[c], V[c]);
+                            uint32_t m = pk_min_u16(a, b);
+                            m = pk_lshr_u16(m, 0x00020000u);  // raw plane: cost >> 2
+                            a32 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, m),
+                                                         __builtin_bit_cast(u16x2_t, 0x00010001u), a32, false);
+                        } else {
+                            // the raw half rounded down to a multiple of 4 (min of the rounded = the rounded min); the
+                            // mask is the third input of the v_bitop3_b32 that ORs the differences
+                            const uint32_t a = (pk_subsat_u16(U[c], V1[c]) | pk_subsat_u16(V0[c], U[c])) & rawmask;
+                            const uint32_t b = (pk_subsat_u16(V[c], U1[c]) | pk_subsat_u16(U0[c], V[c])) & rawmask;
+                            a32 += pk_min_u16(a, b);  // gradient sum | raw sum << 16, plain add
+                        }
                     }
                     cost[j] = a32;
                 }
-                // pack two disparities per register, horizontal window over lanes, vertical running sum
+                // pack two disparities per register
+                uint32_t pp[NP];
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
-                    const uint32_t pp = (cost[2 * k] | (cost[2 * k + 1] << 16)) & keep[k];
-                    const uint32_t T = (CAMD_COST_SCAN_WINDOW && K >= 9) ? lane_window_sum_scan(pp, win_back, win_live)
-                                                                         : lane_window_sum<K>(pp);
+                    if (CAMD_COST_TAIL == 0) {
+                        pp[k] = (cost[2 * k] | (cost[2 * k + 1] << 16)) & keep[k];
+                    } else {
+                        const uint32_t gq = __builtin_amdgcn_perm(cost[2 * k + 1], cost[2 * k], 0x05040100u);  // gradient sums
+                        const uint32_t rq = __builtin_amdgcn_perm(cost[2 * k + 1], cost[2 * k], 0x07060302u);  // raw sums (x 4)
+                        pp[k] = (gq + (rq >> 2)) & keep[k];  // bits 16, 17 of rq are zero: the plain shift is clean
+                    }
+                }
+                // horizontal window over lanes, vertical running sum
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    const uint32_t T = (CAMD_COST_SCAN_WINDOW && K >= 9) ? lane_window_sum_scan(pp[k], win_back, win_live)
+                                                                         : lane_window_sum<K>(pp[k]);
                     const uint32_t old = ring[u][k];
                     ring[u][k] = T;
                     if (SAT) {
@@ -386,10 +469,15 @@ __global__ __launch_bounds__(1024, cost_min_waves(K)) void k_cost(const uint8_t*
                 if (r >= K - 1 && writer) {
                     const int y = y0 + r - (K - 1);
                     uint4* o = reinterpret_cast<uint4*>(outp + (size_t)y * W1 * g.Dp);
-                    *o = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-                    if (SAT) neg_min = pk_min_i16(pk_min_i16(neg_min, pk_min_i16(acc[0], acc[1])), pk_min_i16(acc[2], acc[3]));
-                    if (!SAT && ovf_thresh >= 0)  // (uniform)
-                        ovf_max = pk_max_u16(pk_max_u16(ovf_max, pk_max_u16(acc[0], acc[1])), pk_max_u16(acc[2], acc[3]));
+#pragma unroll
+                    for (int q = 0; q < NP / 4; q++) {
+                        o[q] = make_uint4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                        if (SAT) neg_min = pk_min_i16(pk_min_i16(neg_min, pk_min_i16(acc[4 * q], acc[4 * q + 1])),
+                                                      pk_min_i16(acc[4 * q + 2], acc[4 * q + 3]));
+                        if (!SAT && ovf_thresh >= 0)  // (uniform)
+                            ovf_max = pk_max_u16(pk_max_u16(ovf_max, pk_max_u16(acc[4 * q], acc[4 * q + 1])),
+                                                 pk_max_u16(acc[4 * q + 2], acc[4 * q + 3]));
+                    }
                 }
                 // entries of row r+1 from the rows fetched one step ago; then fetch for row r+2
 #if defined(CAMD_COST_DBG_NOSTAGE) && !defined(CAMD_MEASUREMENT_BUILD)

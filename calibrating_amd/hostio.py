@@ -41,8 +41,17 @@ def _start(t):
 
 
 def to_host(*tensors):
-    """ndarrays of CUDA tensors: all copies queued on the current stream, one synchronisation."""
+    """ndarrays of CUDA tensors: all copies queued on the current stream, one synchronisation.  ONE tensor in -> the
+    bare ndarray out; callers that zip the result with a variable number of keys use ``to_host_list``."""
+    out = to_host_list(*tensors)
+    return out[0] if len(out) == 1 else out
+
+
+def to_host_list(*tensors):
+    """``to_host`` without the single-result unwrapping: always a list, one ndarray per tensor."""
     import torch
+    if not tensors:
+        return []
     if not PINNED or sum(t.numel() * t.element_size() for t in tensors) > PINNED_MAX_BYTES:
         out = [t.cpu().numpy() for t in tensors]
     else:
@@ -50,7 +59,7 @@ def to_host(*tensors):
             staged = [_start(t) for t in tensors]
             torch.cuda.current_stream().synchronize()
         out = [h.numpy() for h in staged]
-    return out[0] if len(out) == 1 else out
+    return out
 
 
 class Sink:

@@ -85,16 +85,32 @@ class Stereo:
         # copies (undistort_rectify_map1/2, rectify_valid_mask1: public attributes in the reference) are lazy.
         self._host, self._dev = {}, {}
 
+    @staticmethod
+    def _dev_key(device):
+        """One spelling per device: torch.device("cuda") and "cuda:0" name the same tables (the current device's)."""
+        import torch
+        d = torch.device(device)
+        if d.type == "cuda" and d.index is None:
+            d = torch.device("cuda", torch.cuda.current_device())
+        return str(d)
+
     def _host_table(self, name, build):
         if name not in self._host:
             if getattr(self, "_bundle_only", False):  # no camera 2 intrinsics to rebuild from: the installed tensors
-                tb = next(v for k, v in self._dev.items() if isinstance(v, dict))
-                un = next(v for k, v in self._dev.items() if k.startswith("unrect:"))
+                tables = [v for k, v in self._dev.items() if not k.startswith("unrect:")]
+                if not tables:
+                    raise RuntimeError("this rig was built from a table bundle but holds no installed tables")
+                tb = tables[0]
                 host = lambda t: t.cpu().numpy()  # noqa: E731
                 self._host.update(map1=(host(tb["map1x"]), host(tb["map1y"])), map2=(host(tb["map2x"]), host(tb["map2y"])),
-                                  mask1=host(tb["mask"]).astype(bool), unrect=(host(un[0]), host(un[1])))
-            else:
-                self._host[name] = build()
+                                  mask1=host(tb["mask"]).astype(bool))
+                un = [v for k, v in self._dev.items() if k.startswith("unrect:")]
+                if un:
+                    self._host["unrect"] = (host(un[0][0]), host(un[0][1]))
+            if name not in self._host:
+                if getattr(self, "_bundle_only", False) and name != "unrect":
+                    raise RuntimeError("table %r cannot be rebuilt on a rig made from a table bundle" % name)
+                self._host[name] = build()  # ("unrect" needs K, R1 and camera 1 only: a bundle rig has them)
         return self._host[name]
 
     @property
@@ -117,8 +133,15 @@ class Stereo:
         """Device-resident tables of this rig: {map1x, map1y, map2x, map2y, mask}, built by the GPU kernel
         (camd_init_undistort_rectify_map; bit-identical to the host properties above) unless a broadcast
         bundle was installed for ``device`` (install_tables)."""
-        key = str(device)
+        key = self._dev_key(device)
         if key not in self._dev:
+            if getattr(self, "_bundle_only", False):
+                # camera 2's intrinsics are not part of a bundle (cam2.K is NaN): rebuilding here would hand back NaN
+                # maps and garbage depth without a word
+                raise RuntimeError("this rig was built from a table bundle installed on %s; it has no tables for %s and "
+                                   "cannot rebuild them (a bundle carries no camera 2 intrinsics) -- install_tables() the "
+                                   "bundle on that device, or load the rig's record there"
+                                   % (sorted(k for k in self._dev if not k.startswith("unrect:")), key))
             m1x, m1y, mask = imgproc.init_undistort_rectify_map(
                 self.cam1.K, self.cam1.D, self.R1, self.K, self.xy, valid_for=self.cam1.xy, device=device)
             m2x, m2y = imgproc.init_undistort_rectify_map(
@@ -157,9 +180,12 @@ class Stereo:
         if (w, h) != tuple(self.xy):
             raise ValueError("bundle is for a %dx%d rectified image, this rig rectifies to %dx%d" % (w, h, *self.xy))
         device = bundle["map1x"].device if device is None else device
-        self._dev[str(device)] = {k: bundle[k] for k in _TABLE_KEYS}
+        key = self._dev_key(device)
+        if self._dev_key(bundle["map1x"].device) != key:
+            raise ValueError("the bundle's tensors live on %s, not on %s" % (bundle["map1x"].device, key))
+        self._dev[key] = {k: bundle[k] for k in _TABLE_KEYS}
         if "unrect_mapx" in bundle:
-            self._dev["unrect:" + str(device)] = (bundle["unrect_mapx"], bundle["unrect_mapy"])
+            self._dev["unrect:" + key] = (bundle["unrect_mapx"], bundle["unrect_mapy"])
         return self
 
     @classmethod
@@ -315,7 +341,7 @@ class Stereo:
 
     def _unrectify_tables(self, device):
         # utils.py:183-191: initUndistortRectifyMap(K, None, R1.T, cam1.K, cam1.xy), memoised per device
-        key = "unrect:" + str(device)
+        key = "unrect:" + self._dev_key(device)
         if key not in self._dev:
             self._dev[key] = imgproc.init_undistort_rectify_map(self.K, None, self.R1.T, self.cam1.K, self.cam1.xy,
                                                                 device=device)
@@ -515,6 +541,7 @@ class Stereo:
                 result.update(undistort_img1=self.undistort_img(i1))
         result = {k: v for k, v in result.items() if want(k)}
         if was_np and result:
-            result = dict(zip(result, hostio.to_host(*result.values())))
+            # (to_host_list: with a single asked key, to_host's bare ndarray would be zipped row by row)
+            result = dict(zip(result, hostio.to_host_list(*result.values())))
             sm.stereo_sgbm.status()  # to_host synchronised: surface device-side timeouts at no extra cost
         return result

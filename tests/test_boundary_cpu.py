@@ -225,3 +225,24 @@ def test_shard_ranges_cover_the_pair_list():
             r = owner_of(i, n, g)
             assert ranges[r][0] <= i < ranges[r][1]
     assert [shard_range(512, 8, r) for r in range(8)] == [(64 * r, 64 * r + 64) for r in range(8)]
+
+
+def test_a_bundle_rig_refuses_to_rebuild_tables_it_was_not_given():
+    """A rig made from a broadcast table bundle has no camera 2 intrinsics (cam2.K is NaN): asked for tables on a
+    device the bundle was not installed on, it must raise -- a silent rebuild would hand back NaN maps and garbage depth.
+    The device key has one spelling (torch.device('cpu') == 'cpu')."""
+    import torch
+    import calibrating_amd as ca
+    from calibrating_amd import synthetic
+    src = ca.Stereo.load(synthetic.rig(96, 64))
+    tabs = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in src.table_bundle().items()}
+    st = ca.Stereo.from_bundle(tabs, "cpu")
+    assert st._tables(torch.device("cpu"))["map2x"] is tabs["map2x"]
+    assert st._unrectify_tables("cpu")[1] is tabs["unrect_mapy"]
+    with pytest.raises(RuntimeError, match="table bundle"):
+        st._tables(torch.device("cuda", 0))  # (no CUDA call is made: the key is compared first)
+    with pytest.raises(ValueError, match="live on"):
+        ca.Stereo.from_bundle(tabs, torch.device("cuda", 1))
+    # the host views come from the installed tensors, whatever else sits in the device cache
+    assert np.array_equal(st.undistort_rectify_map2[0], tabs["map2x"].numpy())
+    assert np.array_equal(st.rectify_valid_mask1, tabs["mask"].numpy().astype(bool))

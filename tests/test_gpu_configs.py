@@ -133,3 +133,12 @@ def test_rig_from_a_table_bundle_alone_equals_the_rig_from_the_record():
     assert all(np.array_equal(gb[k][1], want[k]) for k in want)
     with pytest.raises(ValueError, match="table bundle"):
         worker.dump()  # no R, no camera 2 intrinsics: nothing to write, and it says so
+    # the device key has one spelling: a bundle installed as torch.device("cuda") serves images on "cuda:0" ...
+    w2 = ca.Stereo.from_bundle(bundle, torch.device("cuda"))
+    w2.set_stereo_matching(ca.SemiGlobalBlockMatching(cfg), max_depth=3.5)
+    got2 = w2.get_depth(img1, img2, keys=("rectify_img2", "unrectify_depth"))
+    assert all(np.array_equal(got2[k], want[k]) for k in got2)
+    # ... and a device the bundle was never installed on is an error, not a rebuild from camera 2's NaN intrinsics
+    w2._dev = {k: v for k, v in w2._dev.items() if k.startswith("unrect:")}
+    with pytest.raises(RuntimeError, match="table bundle"):
+        w2.get_depth(img1, img2)

@@ -358,6 +358,14 @@ def test_get_depth_keys_returns_the_asked_entries_only():
     gb = stereo.get_depth_batch(np.stack([img1, img1]), np.stack([img2, img2]), keys=("unrectify_depth", "disparity"))
     assert sorted(gb) == ["disparity", "unrectify_depth"]
     assert all(np.array_equal(gb[k][1], full[k]) for k in gb)
+    # ONE asked key (the documented headline use): the value keeps its leading n -- a single result used to be unwrapped
+    # by hostio.to_host and zipped row by row, which returned pair 0 only, shape (h, w), without a word
+    for key in ("unrectify_depth", "disparity"):
+        g1 = stereo.get_depth_batch(np.stack([img1, img1, img1]), np.stack([img2, img2, img2]), keys=(key,))
+        assert list(g1) == [key] and isinstance(g1[key], np.ndarray) and g1[key].shape == (3,) + full[key].shape
+        assert all(np.array_equal(g1[key][i], full[key]) for i in range(3))
+    g1 = stereo.get_depth_batch(np.stack([img1]), np.stack([img2]), keys="rectify_depth")  # n = 1, one key
+    assert g1["rectify_depth"].shape == (1,) + full["rectify_depth"].shape
     with pytest.raises(ValueError):
         stereo.get_depth_batch(np.stack([img1]), np.stack([img2]), keys=("nope",))
 
