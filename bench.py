@@ -81,6 +81,10 @@ def parse(argv=None):
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (other mode, gray, PCIe)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="strips in the CPU baseline sample (0 = two per thread)")
     ap.add_argument("--lib", default="", help="measurement only: load this build of libcalibrating_amd.so (A/B kernels)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the in-run rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters of one step in a child "
+                         "process); roofline.traffic / valu_frac then come from the committed profiles/ summaries")
+    ap.add_argument("--pmc-budget-s", type=float, default=240.0, help="wall-time budget of the in-run counter passes")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 run: nccl (= RCCL, the product) or gloo (CPU; with --stub-compute)")
     ap.add_argument("--stub-compute", action="store_true",
@@ -91,6 +95,93 @@ def parse(argv=None):
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="time budget of the CPU baseline's thread sweep")
     return ap.parse_args(argv)
+
+
+PMC_SETS = (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]),
+            ("SQ", ["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CU_CYCLES"]))
+
+
+def pmc_in_run(a, nb, budget_s):
+    """HBM traffic and SQ counters of THIS run's kernels: one step of the same workload in a child process under
+    `rocprofv3 --pmc <set> --kernel-trace`, one pass per counter set (FETCH_SIZE and WRITE_SIZE do not fit one pass;
+    MI355X_MICROARCH.md, HBM / rocprofv3 section), no other trace domain.  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB:
+    FETCH_SIZE counts wide coalesced reads at half their size on gfx950 (same guide).  Returns
+    ({"pairs_per_launch", "kernels": {name: {...per-launch averages...}}}, None) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 is not on PATH"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--in-flight", "1",
+             "--batch", str(nb), "--no-also", "--no-cpu-baseline", "--no-pmc", "--width", str(a.width),
+             "--height", str(a.height), "--disparities", str(a.disparities), "--block", str(a.block),
+             "--channels", str(a.channels), "--mode", a.mode, "--path", str(a.path), "--cost", str(a.cost)]
+    if a.lib:
+        child += ["--lib", os.path.abspath(a.lib)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    t_end = time.time() + budget_s
+    per = collections.OrderedDict()
+    tmp = tempfile.mkdtemp(prefix="camd_pmc_", dir="/tmp")
+    try:
+        for tag, ctrs in PMC_SETS:
+            left = t_end - time.time()
+            if left < 20:
+                return None, "the counter passes ran out of their %.0f s budget" % budget_s
+            d = os.path.join(tmp, tag)
+            try:
+                r = subprocess.run([exe, "--pmc"] + ctrs + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p",
+                                                           "--"] + child, cwd="/tmp", env=env, timeout=left,
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s did not finish within the budget" % tag
+            files = glob.glob(os.path.join(d, "**", "*counter_collection*.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (exit %d, %d counter files)" % (tag, r.returncode, len(files))
+            agg, cnt = collections.defaultdict(float), collections.Counter()
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    k = row.get("Kernel_Name", "")
+                    if "camd::" not in k:
+                        continue
+                    k = re.sub(r"^void ", "", k.split("(")[0])
+                    agg[(k, row["Counter_Name"])] += float(row["Counter_Value"])
+                    cnt[(k, row["Counter_Name"])] += 1
+            for (k, c), v in agg.items():
+                per.setdefault(k, {})[c] = v / cnt[(k, c)]  # average per launch
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for k, v in per.items():
+        f, w = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
+        if f is not None and w is not None:
+            v["hbm_bytes_per_launch"] = (2 * f + w) * 1024
+            v["hbm_bytes_per_pair"] = v["hbm_bytes_per_launch"] / nb
+        if v.get("SQ_WAVE_CYCLES"):
+            v["derived"] = {"wait_any_frac": v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]}
+    if not any("hbm_bytes_per_pair" in v for v in per.values()):
+        return None, "no camd:: kernel in the counter files"
+    return {"pairs_per_launch": nb, "kernels": per,
+            "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CU_CYCLES> "
+                       "--kernel-trace -- python bench.py --steps 1 --warmup 1 --in-flight 1 --batch %d (same workload)" % nb}, None
+
+
+def valu_class_mix():
+    """{kernel substring: (fraction of its VALU instructions in the plain 32-bit class, fraction in the packed / DPP /
+    three-operand class)} from the committed listing statistics (profiles/rNN_isa_valu_mix.json, tools/isa_cost.py)."""
+    rel = _latest_profile("isa_valu_mix.json")
+    if not rel:
+        return None, {}
+    doc = json.load(open(os.path.join(ROOT, rel)))
+    return rel, {k: (v["fast_frac"], v["slow_frac"]) for k, v in doc["kernels"].items()}
+
+
+# measured issue rates of the two VALU classes (tools/microtests/valu_rate.hip), wave-instructions per cycle and CU
+RATE_FAST, RATE_SLOW = 1.55, 0.90
 
 
 def sgbm_params(a, mode=None, channels=None):
@@ -724,14 +815,28 @@ def main():
         pmc_other = _latest_profile("pmc_traffic%s.json" % suffix)
         sq_rel = _latest_profile("pmc_sq%s.json" % suffix)
         pmc = sq = None
-        if a.channels == 3 and (a.width, a.height, a.disparities, a.block) == (1920, 1080, 128, 5):
+        pmc_note = "committed profile (--no-pmc)" if a.no_pmc else None
+        if world == 1 and not stub and not a.no_pmc:
+            # counters of THIS run's kernels, taken now (the timed region is over; its buffers are still allocated,
+            # the child needs its own ~1.3 GB per pair)
+            torch.cuda.empty_cache()
+            inrun, why = pmc_in_run(a, nb, a.pmc_budget_s)
+            if inrun:
+                pmc = sq = inrun
+                pmc_rel = sq_rel = "in-run: " + inrun["command"]
+                pmc_other = None
+            else:
+                pmc_note = "committed profile (in-run counters unavailable: %s)" % why
+        if pmc is None and a.channels == 3 and (a.width, a.height, a.disparities, a.block) == (1920, 1080, 128, 5):
             pmc = json.load(open(os.path.join(ROOT, pmc_rel))) if pmc_rel else None
             sq = json.load(open(os.path.join(ROOT, sq_rel))) if sq_rel else None
+        mix_rel, mix = valu_class_mix()
 
         def pmc_bytes_per_pair(keys):
             if not pmc:
                 return None
-            hit = [v["hbm_bytes_per_pair"] for k, v in pmc["kernels"].items() if all(s in k for s in keys)]
+            hit = [v["hbm_bytes_per_pair"] for k, v in pmc["kernels"].items()
+                   if all(s in k for s in keys) and "hbm_bytes_per_pair" in v]
             return hit[0] if len(hit) == 1 else None
 
         def sq_counters(keys):
@@ -763,11 +868,24 @@ def main():
                 # `wave_wait_frac` = share of wave cycles in s_waitcnt / s_barrier
                 vf = vi * nb / (N_CUS * CLOCK_HZ) / (ms * 1e-3)
                 hf = ach / HBM_PEAK_GBS
+                # the kernel's own issue floor: its instructions at the measured rates of their two classes (the plain
+                # 32-bit forms issue at ~1.55 per cycle and CU, packed / DPP / three-operand forms at ~0.9)
+                shape = ("k_cost<%d, %d," % (a.channels, a.block),) if st == "cost" else \
+                    ("k_band<16, %d," % ((a.disparities + 31) // 32),) if st in ("scan", "scan_last") else ()
+                ff, fs = next((m for k, m in mix.items() if all(s_ in k for s_ in keys + shape)), (0.0, 1.0))
+                floor_ms = vi * nb * (ff / RATE_FAST + fs / RATE_SLOW) / (N_CUS * CLOCK_HZ) * 1e3
                 kernels[st].update(valu_wave_insts_per_launch=vi * nb, valu_frac=vf, wave_wait_frac=waitf,
-                                   bound="valu" if vf >= 0.8 else "hbm" if hf >= 0.6 else "latency")
+                                   valu_plain_class_frac=ff, valu_floor_ms=floor_ms,
+                                   hbm_floor_ms=(tr * nb / (HBM_PEAK_GBS * 1e9) * 1e3) if tr is not None else None,
+                                   bound="valu" if floor_ms >= 0.8 * ms else "hbm" if hf >= 0.6 else "latency")
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms_per_launch"]) if kernels else None
         # whole-step traffic = every kernel of the committed PMC profile (incl. the small init / check kernels)
-        traffic_total = sum(v["hbm_bytes_per_pair"] for v in pmc["kernels"].values()) * nb if pmc else None
+        traffic_total = sum(v.get("hbm_bytes_per_pair", 0.0) for v in pmc["kernels"].values()) * nb if pmc else None
+        # the step's two floors: every VALU instruction of its kernels at the issue rate of its class, and every HBM byte
+        # the counters saw at the 8 TB/s peak -- what the step would take if one of the two were the only limit
+        floors = [k.get("valu_floor_ms") for k in kernels.values()]
+        valu_floor_ms = sum(f for f in floors if f is not None) if any(f is not None for f in floors) else None
+        hbm_floor_ms = traffic_total / (HBM_PEAK_GBS * 1e9) * 1e3 if traffic_total else None
         achieved = b_alg * nb / (gpu_ms_step * 1e-3) / 1e9
         # the same ratio from the profile taken at another number of pairs per launch, when it differs by more than 2 %
         other_ratio = None
@@ -800,8 +918,14 @@ def main():
                 "gpu_ms_per_step": gpu_ms_step, "kernel_ms_per_step": kernel_ms_step,
                 "traffic": traffic_total,
                 "traffic_ratio": (traffic_total / (b_alg * nb)) if traffic_total else None,
-                "traffic_source": (pmc_rel + " (bytes per pair per launch x pairs per launch; profile taken at %s pairs per "
+                "traffic_source": (pmc_rel + " (bytes per pair per launch x pairs per launch; taken at %s pairs per "
                                              "launch)" % pmc.get("pairs_per_launch")) if pmc else None,
+                "counters": "in-run" if (pmc and str(pmc_rel).startswith("in-run")) else pmc_note,
+                # what the step would take if VALU issue / HBM bytes were its only limit, next to what it took
+                "valu_floor_ms": valu_floor_ms, "hbm_floor_ms": hbm_floor_ms,
+                "frac_of_valu_floor": (valu_floor_ms / gpu_ms_step) if valu_floor_ms else None,
+                "frac_of_hbm_floor": (hbm_floor_ms / gpu_ms_step) if hbm_floor_ms else None,
+                "valu_class_mix_source": mix_rel,
                 "traffic_ratio_other_profile": other_ratio,
                 "valu_source": (sq_rel + " (SQ_INSTS_VALU per pair x pairs per launch / (%d CUs x %.1f GHz) / this run's "
                                          "kernel time)" % (N_CUS, CLOCK_HZ / 1e9)) if sq else None,

@@ -45,8 +45,6 @@ SIGNATURES = {
     "camd_last_error": (ctypes.c_char_p, []),
     "camd_version": (c_int, []),
     "camd_device_ok": (c_int, []),
-    "camd_stream_create_cu_mask": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p)]),
-    "camd_stream_destroy": (c_int, [c_void_p]),
     "camd_sgbm_workspace_bytes": (c_size_t, [ctypes.POINTER(SgbmParams), c_int, c_int, c_int, c_int]),
     "camd_sgbm_create": (c_int, [ctypes.POINTER(SgbmParams), c_int, c_int, c_int, c_int,
                                  ctypes.POINTER(c_void_p)]),
@@ -96,6 +94,14 @@ SIGNATURES = {
                                      c_int, c_int, c_int, c_void_p]),
 }
 
+# include/calibrating_amd_experimental.h: measurement hooks without a counterpart in the reference's interface (CU-masked
+# streams; with them goes set_option's CAMD_OPT_PHASES = 6).  Bound so that tools/ and one parity test can reach them;
+# nothing in this package calls them.
+EXPERIMENTAL_SIGNATURES = {
+    "camd_stream_create_cu_mask": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p)]),
+    "camd_stream_destroy": (c_int, [c_void_p]),
+}
+
 
 def lib():
     """The loaded library (declares every signature on first use)."""
@@ -109,7 +115,7 @@ def lib():
         # HIP runtime instance, so device pointers and streams are shared with torch
         import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(EXPERIMENTAL_SIGNATURES.items()):
             fn = getattr(l, name)  # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args

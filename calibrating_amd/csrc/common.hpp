@@ -8,6 +8,7 @@
 #include <cstdio>
 
 #include "../../include/calibrating_amd.h"
+#include "../../include/calibrating_amd_experimental.h"  // (the library implements these too; the product never calls them)
 
 namespace camd {
 

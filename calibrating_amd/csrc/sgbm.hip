@@ -795,13 +795,15 @@ struct camd_sgbm {
     int keep_S;           // band path: also store S in the final pass (stage-wise parity hook)
     int cost_path;        // CAMD_COST_*
     int saturate;         // U7: 1 = C saturates like OpenCV's CV_SIMD build (default), 0 = wraps like the scalar build
-    int phases;           // CAMD_OPT_PHASES: bit 0 = build the cost volume, bit 1 = aggregate + post (default 3 = both)
+    int phases;           // CAMD_OPT_PHASES (experimental): bit 0 = build the cost volume, bit 1 = first aggregation pass,
+                          // bit 2 = last pass + winner-take-all + post filters (default 7 = everything)
     int nbands, nchunks;
     size_t erec_stride;
     unsigned long long* E;
     uint32_t *flags, *ticket, *err, *keys;
     uint32_t* xbar;       // grid-barrier counter of the exact path's persistent kernel (sgbm_exact.hpp)
     int num_cus;          // compute units of the device the handle lives on
+    int persist_cost, persist_row;  // CAMD_OPT_RESIDENT (experimental): workgroups per CU of k_cost_persist / k_band_row_persist, 0 = off
     uint32_t* err_host;   // pinned mirror of *err, refreshed by an async copy after every band-path compute
     int16_t* d1;
     uint32_t epoch;
@@ -1083,6 +1085,12 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
         else CAMD_BAND_TIE(2, 4);
 #undef CAMD_BAND_TIE
     }
+    else if (!full && mode == 2 && h->persist_row > 0 && g.lanes == 16 && g.nr == 4) {
+        // CAMD_OPT_RESIDENT: a fixed number of resident workgroups, runs of rows by ticket (sgbm_band.hpp)
+        const dim3 pgrid(h->persist_row * h->num_cus);
+        if (pad) hipLaunchKernelGGL((k_band_row_persist<16, 4, true>), pgrid, block, 0, st, a, g);
+        else hipLaunchKernelGGL((k_band_row_persist<16, 4, false>), pgrid, block, 0, st, a, g);
+    }
     else if (!full && mode == 2) CAMD_FOR_BAND_SHAPE(g, CAMD_BAND_R2);
     else if (!full && mode == 1) CAMD_FOR_BAND_SHAPE(g, CAMD_BAND_R1);
     else { set_error("band pass (full %d, mode %d) not instantiated", (int)full, mode); return CAMD_ERR_UNSUPPORTED; }
@@ -1257,6 +1265,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     if (e == hipSuccess) e = hipMemset(h->ticket, 0, 16);
     h->err = h->ticket ? h->ticket + 1 : nullptr;
     h->xbar = h->ticket ? h->ticket + 2 : nullptr;
+    h->persist_cost = h->persist_row = 0;   // (ticket[3]: k_cost_persist's item counter)
     {
         int dev = 0, ncu = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
@@ -1271,7 +1280,7 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
     h->band_ok = band_supported(g);
     h->path = 0;
     h->saturate = 1;
-    h->phases = 3;
+    h->phases = 7;
     h->epoch = 0;
     if (h->band_ok) {
         const int R = BAND_THREADS / g.lanes;
@@ -1380,7 +1389,11 @@ int camd_sgbm_set_option(camd_sgbm* h, int option, int value)
     else if (option == CAMD_OPT_COST && value >= CAMD_COST_AUTO && value <= CAMD_COST_SPLIT) h->cost_path = value;
     else if (option == CAMD_OPT_SATURATE) h->saturate = value != 0;
     else if (option == CAMD_OPT_3WAY_SIMD_LANES && (value == 1 || value == 8)) h->way3_simd_lanes = value;
-    else if (option == CAMD_OPT_PHASES && value >= 1 && value <= 3) h->phases = value;
+    else if (option == CAMD_OPT_PHASES && value >= 1 && value <= 7) h->phases = value;
+    else if (option == CAMD_OPT_RESIDENT && value >= 0 && (value >> 4) <= 4 && (value & 15) <= 4) {
+        h->persist_cost = value >> 4;
+        h->persist_row = value & 15;
+    }
     else if (option == CAMD_OPT_EXACT) {
         if (value != 0 && !h->Lx && h->may_overflow) {
             // the workspace could not be had when the handle was made: try again rather than stay in refuse mode silently
@@ -1522,10 +1535,31 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
                     }
                 }
             }
+            // CAMD_OPT_RESIDENT: a fixed number of resident workgroups take the same items by ticket (k_cost_persist), in
+            // smaller row chunks so that the last items of the launch end together
+            const bool resident = h->persist_cost > 0 && !sat_kernel && !ovf && h->cr.n == 1 && (K == 5 || K == 3) && !dl16 &&
+                                  g.D % (nw * dl) == 0;
+            if (resident) {
+                const long long per_chunk = (long long)nstrips * ndblk * vbatch;
+                const int maxc = h->ga.H / 32 > 1 ? h->ga.H / 32 : 1;
+                nchunks = div_up(24LL * h->persist_cost * h->num_cus, per_chunk);
+                nchunks = nchunks < 1 ? 1 : (nchunks > maxc ? maxc : nchunks);
+            }
             const int rb = div_up(h->ga.H, nchunks);  // rows per chunk, in the longest range
             nchunks = div_up(h->ga.H, rb);
             dim3 grid(nstrips, nchunks * ndblk, vbatch), block(64 * nw);
             const size_t lds = cost_lds_bytes(g.cn, nw, dl);
+            if (resident) {
+                uint32_t* tk = h->ticket + 3;  // (zeroed below, before the launches)
+                const int nx = nstrips, ny = nchunks * ndblk, nitems = nx * ny * vbatch;
+                const dim3 pgrid(h->persist_cost * h->num_cus);
+#define CAMD_COSTP(CNN, KK) hipLaunchKernelGGL((k_cost_persist<CNN, KK>), pgrid, block, lds, st, left, right, pitch, image_stride, \
+                                               h->C, g, rb, nchunks, h->vol_elems, h->cr, tk, nx, ny, nitems)
+                if (g.cn == 1) { if (K == 5) CAMD_COSTP(1, 5); else CAMD_COSTP(1, 3); }
+                else { if (K == 5) CAMD_COSTP(3, 5); else CAMD_COSTP(3, 3); }
+#undef CAMD_COSTP
+                return;
+            }
 #define CAMD_COST_DLX(CNN, KK, SS, DLL)                                                                                   \
     hipLaunchKernelGGL((k_cost<CNN, KK, SS, DLL>), grid, block, lds, st, left, right, pitch, image_stride, h->C, g, rb, \
                        nchunks, h->vol_elems, h->cr, ovf, thresh, h->cost_neg)
@@ -1547,6 +1581,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
 #undef CAMD_COST_DLX
         };
         if (may_overflow) CAMD_HIP(hipMemsetAsync(h->cost_neg, 0, (size_t)vbatch * 4, st));
+        if (h->persist_cost > 0) CAMD_HIP(hipMemsetAsync(h->ticket + 3, 0, 4, st));
         if (two_stage) {
             CAMD_HIP(hipMemsetAsync(h->cost_ovf, 0, (size_t)vbatch * 4, st));
             launch_cost(false, h->cost_ovf, 32767 - tbound);
@@ -1618,10 +1653,12 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         CAMD_LAUNCH_CHECK();
     }
 
-    if (!(h->phases & 2)) {  // CAMD_OPT_PHASES: the caller runs the aggregation in a second call (another stream)
+    if (!(h->phases & 6)) {  // CAMD_OPT_PHASES: the caller runs the aggregation in a second call (another stream)
         for (int i = ST_SCAN; i <= ST_COUNT; i++) MARK(i);
         return CAMD_OK;
     }
+    // (the split between the two aggregation passes exists on the plain band path only; elsewhere bits 1 and 2 travel together)
+    const bool ph_first = (h->phases & 2) != 0, ph_last = (h->phases & 4) != 0;
 
     // aggregation path: fused band passes win on throughput (>= ~8 pairs per launch), concurrent
     // per-direction scans on latency (a few pairs: every direction gets its own S volume and all of them
@@ -1679,13 +1716,20 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
         if (rc != CAMD_OK) return rc;
     } else if (band) {
         // fused passes: every pass reads C once and touches S once for up to four directions
-        size_t npix = (size_t)batch * g.H * g.W;
-        hipLaunchKernelGGL(k_wta_init, dim3(div_up((long long)npix, 256)), dim3(256), 0, st, h->keys, h->d1, npix,
-                           (g.minD - 1) * 16);
-        CAMD_LAUNCH_CHECK();
-        int rc = launch_band(h, +1, +1, true, 0, batch, st, g.mode != CAMD_MODE_HH4);          // ->  v  [\.  ./]
-        if (rc != CAMD_OK) return rc;
+        int rc = CAMD_OK;
+        if (ph_first) {
+            size_t npix = (size_t)batch * g.H * g.W;
+            hipLaunchKernelGGL(k_wta_init, dim3(div_up((long long)npix, 256)), dim3(256), 0, st, h->keys, h->d1, npix,
+                               (g.minD - 1) * 16);
+            CAMD_LAUNCH_CHECK();
+            rc = launch_band(h, +1, +1, true, 0, batch, st, g.mode != CAMD_MODE_HH4);          // ->  v  [\.  ./]
+            if (rc != CAMD_OK) return rc;
+        }
         MARK(ST_SCAN2);
+        if (!ph_last) {
+            for (int i = ST_WTA; i <= ST_COUNT; i++) MARK(i);
+            return CAMD_OK;
+        }
         if (g.mode == CAMD_MODE_HH4) rc = launch_band(h, -1, -1, true, 2, batch, st, false);    // <-  ^ + WTA
         else if (g.mode == CAMD_MODE_HH) rc = launch_band(h, -1, -1, true, 2, batch, st);       // <-  ^  \^  /^ + WTA
         else rc = launch_band(h, -1, +1, false, 2, batch, st);                                  // <- + WTA

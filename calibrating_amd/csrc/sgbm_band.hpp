@@ -51,6 +51,9 @@ namespace camd {
 #ifndef CAMD_BAND_HELPER_WAVE
 #define CAMD_BAND_HELPER_WAVE CAMD_BAND_COMPUTE_WAVES    // !MERGED: which wave of the workgroup is the helper (default: the last)
 #endif
+#ifndef CAMD_ROW_PERSIST_PRIO
+#define CAMD_ROW_PERSIST_PRIO 3                          // s_setprio of k_band_row_persist's waves (0 = leave it)
+#endif
 #ifndef CAMD_BAND_DUTY_WAVE
 #define CAMD_BAND_DUTY_WAVE 0                            // MERGED: the compute wave that also feeds the edge ring
 #endif
@@ -275,11 +278,14 @@ __device__ __forceinline__ void band_wta_flush(const BandArgs& a, const Geom& g,
 // FULL: H, V, Dg, A of sweep (sx, sy), skew 2.  !FULL: H of sweep sx only (rows independent).
 // MODE: 0 = first pass (S written), 2 = final (S read, WTA; S stored only for the parity hook)
 // DIAG = false (MODE_HH4): the two diagonal directions are left out (their slots travel as zeros)
-template <int LANES, int NR, bool FULL, int MODE, bool PAD, bool DIAG = true, bool TIE8 = false>
-__global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES : CAMD_BAND_ROW_MIN_WAVES) : 2) void k_band(BandArgs a, Geom g)
+// ALLW (row-parallel pass only): all waves of the workgroup compute (rows per ticket = BAND_BLOCK / LANES)
+// ticket: the (pair, band) / run of rows this call works on (k_band: one per workgroup; k_band_row_persist: a loop)
+template <int LANES, int NR, bool FULL, int MODE, bool PAD, bool DIAG, bool TIE8, bool ALLW>
+__device__ __forceinline__ void band_body(const BandArgs& a, const Geom& g, const int ticket)
 {
+    static_assert(!(FULL && ALLW), "the wavefront pass keeps its helper wave");
     constexpr int NQ = (NR + 3) / 4;  // 16-byte LDS slots / u64 edge-record pairs per lane and vector
-    constexpr int NTH = (!FULL && CAMD_BAND_ROW_ALL_WAVES) ? BAND_BLOCK : BAND_THREADS;  // compute threads of a workgroup
+    constexpr int NTH = (!FULL && ALLW) ? BAND_BLOCK : BAND_THREADS;  // compute threads of a workgroup
     static_assert(!CAMD_BAND_MERGED || BAND_BLOCK == BAND_THREADS, "merged helper duty: every wave computes");
     constexpr int R = NTH / LANES;
     constexpr int EVEC = 6 * NQ;     // u64 per lane per column: V (2NQ), Dg (2NQ), A (2NQ)
@@ -297,11 +303,7 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
     __shared__ uint4 eA[3][EN];
     __shared__ uint4 edl[3][FULL ? CPB : 1];
     __shared__ uint4 wS[MODE == 2 ? NQ * R * (LANES + WtaPad<LANES>::Q) : 1];  // FINAL: S of the current pixel, per group
-    __shared__ uint32_t s_ticket;
 
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1u);
-    __syncthreads();
-    const int ticket = (int)s_ticket;
     // band-major order: band b of every pair is handed out before band b+1 of any pair, so with many
     // pairs in flight a workgroup's upstream band is usually far ahead by the time it starts (the
     // dependency (pair, b-1) always holds an earlier ticket)
@@ -311,9 +313,9 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
     // compute thread index).  Which wave helps decides which SIMD carries one compute wave less (see
     // tools/microtests/wave_simd_placement.hip)
     const int wv = threadIdx.x >> 6;
-    const bool helper = !CAMD_BAND_MERGED && (FULL || !CAMD_BAND_ROW_ALL_WAVES) && wv == BAND_HELPER_WAVE;  // wave-uniform
+    const bool helper = !CAMD_BAND_MERGED && (FULL || !ALLW) && wv == BAND_HELPER_WAVE;  // wave-uniform
     if (!FULL && helper) return;
-    const int ctid = (CAMD_BAND_MERGED || (!FULL && CAMD_BAND_ROW_ALL_WAVES)) ? (int)threadIdx.x
+    const int ctid = (CAMD_BAND_MERGED || (!FULL && ALLW)) ? (int)threadIdx.x
                      : helper ? (int)(threadIdx.x & 63) : (((wv > BAND_HELPER_WAVE ? wv - 1 : wv) << 6) | (int)(threadIdx.x & 63));
     const int grp = ctid / LANES, li = ctid % LANES;
     const int W1 = g.W1, H = g.H;
@@ -625,6 +627,40 @@ __global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES :
 #endif
             }
         }
+    }
+}
+
+template <int LANES, int NR, bool FULL, int MODE, bool PAD, bool DIAG = true, bool TIE8 = false>
+__global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? (FULL ? CAMD_BAND_MIN_WAVES : CAMD_BAND_ROW_MIN_WAVES) : 2) void k_band(BandArgs a, Geom g)
+{
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    band_body<LANES, NR, FULL, MODE, PAD, DIAG, TIE8, !FULL && CAMD_BAND_ROW_ALL_WAVES>(a, g, (int)s_ticket);
+}
+
+// The row-parallel last pass with a FIXED number of resident workgroups (grid = workgroups per CU x 256) that take runs
+// of BAND_BLOCK / LANES rows by ticket until the batch is done: the counterpart of k_cost_persist (sgbm_cost.hpp) --
+// launched this way the pass leaves room on every CU for the cost kernel of the next batch.
+template <int LANES, int NR, bool PAD, bool TIE8 = false>
+__global__ __launch_bounds__(BAND_BLOCK, NR <= 4 ? CAMD_BAND_ROW_MIN_WAVES : 2) void k_band_row_persist(BandArgs a, Geom g)
+{
+    __shared__ uint32_t s_ticket;
+    const long long rows = (long long)a.npairs * g.H;
+    // Beside the cost kernel's waves -- older, and ready to issue VALU every cycle -- these waves would get the issue
+    // slots that are left over ("priority, then age"), i.e. next to none, and the pass would crawl until the cost kernel
+    // is done.  Raised priority gives the pass the ~half of the VALU issue it needs to keep HBM busy; the cost kernel
+    // takes the rest.
+#if CAMD_ROW_PERSIST_PRIO
+    __builtin_amdgcn_s_setprio(CAMD_ROW_PERSIST_PRIO);
+#endif
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        const int ticket = (int)s_ticket;
+        __syncthreads();
+        if ((long long)ticket * (BAND_BLOCK / LANES) >= rows) break;
+        band_body<LANES, NR, false, 2, PAD, true, TIE8, true>(a, g, ticket);
     }
 }
 

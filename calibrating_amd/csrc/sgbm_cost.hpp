@@ -156,11 +156,14 @@ constexpr int cost_min_waves(int K, int DL = COST_DL)
     return DL > 8 ? CAMD_COST_MIN_WAVES_DL16 : (K >= 11 ? 4 : (K >= 9 ? 5 : CAMD_COST_MIN_WAVES));
 }
 
-template <int CN, int K, bool SAT, int DL = COST_DL>
-__global__ __launch_bounds__(1024, cost_min_waves(K, DL)) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
-                                               size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
-                                               Geom g, int rb, int nchunks, size_t vol_stride, CostRanges cr,
-                                               uint32_t* __restrict__ ovf, int ovf_thresh, uint32_t* __restrict__ neg)
+// the work of one (strip bx, row chunk x disparity block by, volume bz) -- k_cost's workgroup, or one item of a
+// persistent workgroup (k_cost_persist)
+template <int CN, int K, bool SAT, int DL>
+__device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                          size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
+                                          const Geom& g, int rb, int nchunks, size_t vol_stride, const CostRanges& cr,
+                                          uint32_t* __restrict__ ovf, int ovf_thresh, uint32_t* __restrict__ neg,
+                                          const int bx, const int by, const int bz)
 {
     constexpr int ES = CN == 1 ? 4 : 12;  // dwords per staged entry: (p, lo, hi) per channel, padded to 16 bytes
     constexpr int EV = ES / 4;
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(1024, cost_min_waves(K, DL)) void k_cost(const uint
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6, DW = NW * DL;
     const int tid = threadIdx.x;
-    const int chunk = blockIdx.y % nchunks, dblk = blockIdx.y / nchunks;
-    const int vpair = blockIdx.z, pair = vpair / cr.n, ridx = vpair % cr.n;  // volume index, image index, range
+    const int chunk = by % nchunks, dblk = by / nchunks;
+    const int vpair = bz, pair = vpair / cr.n, ridx = vpair % cr.n;  // volume index, image index, range
     const int ybase = cr.start[ridx], nrows = cr.rows[ridx];
     if (chunk * rb >= nrows) return;  // (ranges shorter than the longest one: whole workgroup, before any barrier)
     // Two-stage build of a saturating volume (sgbm.hip): the wrapping kernel (SAT = false, rows in parallel chunks)
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(1024, cost_min_waves(K, DL)) void k_cost(const uint
     // it lost, and a volume with C < P2 is outside the regime of the packed-u16 aggregation kernels (sgbm_exact.hpp)
     uint32_t neg_min = SENT_PK;
     const int W1 = g.W1, H = g.H;
-    const int xo0 = blockIdx.x * XS, xs0 = xo0 - SW2;                 // first output column, column of lane 0
+    const int xo0 = bx * XS, xs0 = xo0 - SW2;                 // first output column, column of lane 0
     const int cmin = max(xs0, 0), cmax = min(xs0 + 63, W1 - 1);       // clamped column range of the strip
     const int cx = min(max(xs0 + lane, 0), W1 - 1);                   // this lane's (clamped) cost column
     const int db = dblk * DW;                                         // first disparity index of the block
@@ -493,6 +496,41 @@ __global__ __launch_bounds__(1024, cost_min_waves(K, DL)) void k_cost(const uint
     }
     if (!SAT && ovf_thresh >= 0 && (int)max(ovf_max & 0xffffu, ovf_max >> 16) > ovf_thresh) atomicOr(ovf + vpair, 1u);
     if (SAT && neg && min((int)(int16_t)(neg_min & 0xffffu), (int)(int16_t)(neg_min >> 16)) < g.P2) atomicOr(neg + vpair, 1u);
+}
+
+template <int CN, int K, bool SAT, int DL = COST_DL>
+__global__ __launch_bounds__(1024, cost_min_waves(K, DL)) void k_cost(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                               size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
+                                               Geom g, int rb, int nchunks, size_t vol_stride, CostRanges cr,
+                                               uint32_t* __restrict__ ovf, int ovf_thresh, uint32_t* __restrict__ neg)
+{
+    cost_body<CN, K, SAT, DL>(left, right, pitch, image_stride, Cout, g, rb, nchunks, vol_stride, cr, ovf, ovf_thresh, neg,
+                              (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// The same work handed out by a ticket to a FIXED number of resident workgroups (grid = workgroups per CU x 256): a
+// launch that does not fill the chip, so that the workgroups of another kernel -- the HBM-bound last aggregation pass of
+// the previous batch, launched the same way on another stream -- are resident beside it for its whole duration.  (Two
+// ordinary launches on two streams only overlap in their tails: the dispatcher drains the older grid first --
+// profiles/r06_corun.json.)  Items are numbered strip-fastest like k_cost's grid.  Only for launches in which no wave
+// leaves early (numDisparities a multiple of the workgroup's disparity block) and no per-volume early exit applies.
+template <int CN, int K, int DL = COST_DL>
+__global__ __launch_bounds__(1024, cost_min_waves(K, DL)) void k_cost_persist(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                               size_t pitch, size_t image_stride, uint16_t* __restrict__ Cout,
+                                               Geom g, int rb, int nchunks, size_t vol_stride, CostRanges cr,
+                                               uint32_t* __restrict__ ticket, int nx, int ny, int nitems)
+{
+    __shared__ int s_item;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = (int)atomicAdd(ticket, 1u);
+        __syncthreads();
+        const int item = s_item;
+        __syncthreads();
+        if (item >= nitems) break;
+        const int bx = item % nx, r = item / nx;
+        cost_body<CN, K, false, DL>(left, right, pitch, image_stride, Cout, g, rb, nchunks, vol_stride, cr, nullptr, -1, nullptr,
+                                    bx, r % ny, r / ny);
+    }
 }
 
 }  // namespace camd

@@ -62,12 +62,23 @@ class StereoSGBM:
         'exact': a pair whose cost volume left the int16 regime of the fast kernels (only after an overflow of the box
         sums on adversarial images) is 1 = aggregated again in plain int arithmetic (default), 0 = refused (written
         as invalid, status() / the next compute raise);
-        'phases': what a compute() call queues, 1 = the cost volume only, 2 = aggregation + post only (on the volume the
-        previous phase-1 call built), 3 = both (default) -- for callers that pipeline the two over two streams."""
-        opt = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3, "way3_simd_lanes": 4, "exact": 5, "phases": 6}[option]
+        'phases' / 'resident': measurement hooks (include/calibrating_amd_experimental.h; tools/ only) -- which of
+        {1 cost volume, 2 first aggregation pass, 4 last pass + post} a compute() queues (default 7), and 16 a + b
+        persistent workgroups per CU for the cost kernel / the row-parallel last pass (default 0 = ordinary launches).
+        Every cached workspace takes the value or none does: a refusal rolls the others back before it is raised."""
+        names = {"path": 0, "keep_S": 1, "cost": 2, "saturate": 3, "way3_simd_lanes": 4, "exact": 5, "phases": 6, "resident": 7}
+        defaults = {0: 0, 1: 0, 2: 0, 3: 1, 4: 8, 5: 1, 6: 7, 7: 0}
+        opt, value = names[option], int(value)
+        lib, applied = _native.lib(), []
         for hd, _, _ in self._cache.values():
-            _native.check(_native.lib().camd_sgbm_set_option(hd, opt, int(value)))  # (a refused value is not remembered)
-        self._options[opt] = int(value)
+            rc = lib.camd_sgbm_set_option(hd, opt, value)
+            if rc != _native.CAMD_OK:
+                msg = _native.last_error()
+                for done in applied:  # (the previous value was accepted once, so this cannot be refused)
+                    lib.camd_sgbm_set_option(done, opt, self._options.get(opt, defaults[opt]))
+                raise ValueError("StereoSGBM.set_option(%r, %d): %s" % (option, value, msg))
+            applied.append(hd)
+        self._options[opt] = value
         return self
 
     def status(self):

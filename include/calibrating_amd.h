@@ -39,16 +39,6 @@ int camd_version(void);
 /* 0 when a gfx950 device is usable by this process, CAMD_ERR_NO_DEVICE otherwise */
 int camd_device_ok(void);
 
-/* A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): bit i of cu_mask[i / 32]
- * enables CU i in the driver's enumeration, which walks the XCDs first -- bit 0 = XCD 0's first CU, bit 1 = XCD 1's,
- * ... -- so the first N bits are N / 8 CUs of every XCD (measured: tools/gpu_cumask_probe.py).  An XCD whose share of
- * the mask is empty is left unrestricted, not disabled, and workgroups are dealt to the XCDs in equal shares: give
- * every XCD the same number of CUs, a multiple of its four shader engines (N a multiple of 32).  For spatial partitioning of concurrent work (one partition
- * for a VALU-bound kernel, the rest for an HBM-bound one).  The reference has no counterpart (single-threaded host
- * code); nothing on the default path creates such a stream.  *stream is a hipStream_t. */
-int camd_stream_create_cu_mask(const uint32_t* cu_mask, int nwords, void** stream);
-int camd_stream_destroy(void* stream);
-
 /* ---- SGBM ------------------------------------------------------------------------------------
  * replaces cv2.StereoSGBM_create(...) and .compute(left, right):
  *   stereo_matching.py:48-58 (create; field order = keyword order there, plus preFilterCap, mode)
@@ -75,10 +65,14 @@ typedef struct camd_sgbm camd_sgbm;
 size_t camd_sgbm_workspace_bytes(const camd_sgbm_params* p, int width, int height, int channels,
                                  int max_batch);
 /* Allocates the per-pair workspace for `max_batch` pairs of width x height x channels (1 or 3) u8.
- * Parameters are normalised as cv2 does (numDisparities rounded up to 16, P1 / P2 defaults, blockSize made odd ...).
- * Refused with CAMD_ERR_UNSUPPORTED and a message, never computed differently: numDisparities > 512, blockSize > 15
- * (> 11 for MODE_SGBM_3WAY), P2 > 24000, preFilterCap > 127, 0 < width - numDisparities <= blockSize / 2 (cv2's own
- * result is undefined there), MODE_SGBM_3WAY on images too low for its four stripes. */
+ * Parameters are normalised as cv2's computeDisparitySGBM does and no further: numDisparities is used AS GIVEN (218 stays
+ * 218; only the internal volume is padded, to a multiple of 32 above 64), blockSize <= 0 -> 5 and otherwise only its
+ * half blockSize / 2 is used (an even size acts as the next odd one, as in cv2), P1 <= 0 -> 2, P2 <= 0 -> 5, then
+ * P2 = max(P2, P1 + 1), uniquenessRatio < 0 -> 10, disp12MaxDiff <= 0 -> 1, preFilterCap -> max(cap, 15) | 1.
+ * Refused with CAMD_ERR_UNSUPPORTED and a message, never computed differently (cv2.StereoSGBM_create accepts all of
+ * these; INTEGRATION.md section D says what each limit comes from): numDisparities > 512, blockSize > 15 (> 11 for
+ * MODE_SGBM_3WAY), P2 > 24000, preFilterCap > 127, 0 < width - numDisparities <= blockSize / 2 (cv2's own result is
+ * undefined there), MODE_SGBM_3WAY on images too low for its four stripes. */
 int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int channels, int max_batch,
                      camd_sgbm** out);
 int camd_sgbm_destroy(camd_sgbm* h);
@@ -105,7 +99,7 @@ int camd_sgbm_debug_copy(camd_sgbm* h, int which, int index, void* dst, void* st
  * (where D allows; the winners are decided inside the last pass for D % 8 == 0, by a separate kernel otherwise).
  * CAMD_OPT_KEEP_S 1 = the band path also stores the final S volume (for camd_sgbm_debug_copy(which = 1)). */
 enum { CAMD_OPT_PATH = 0, CAMD_OPT_KEEP_S = 1, CAMD_OPT_COST = 2, CAMD_OPT_SATURATE = 3, CAMD_OPT_3WAY_SIMD_LANES = 4,
-       CAMD_OPT_EXACT = 5, CAMD_OPT_PHASES = 6 };
+       CAMD_OPT_EXACT = 5 };  /* (6 = CAMD_OPT_PHASES: calibrating_amd_experimental.h) */
 enum { CAMD_PATH_AUTO = 0, CAMD_PATH_SCAN = 1, CAMD_PATH_BAND = 2, CAMD_PATH_CONCURRENT = 3 };
 /* CAMD_OPT_COST selects how the matching-cost volume C is built (bit-identical results):
  *   CAMD_COST_AUTO (default)  the fused kernel where it is instantiated (blockSize <= 11), else the split pair
@@ -127,12 +121,7 @@ enum { CAMD_COST_AUTO = 0, CAMD_COST_FUSED = 1, CAMD_COST_SPLIT = 2 };
  *                of per-direction volumes of workspace)
  *   0            it is refused: its disparities are written as invalid and camd_sgbm_status / the next
  *                camd_sgbm_compute return CAMD_ERR_HIP (also what happens when that workspace could not be allocated)
- * Either way a result that differs from OpenCV's is never handed back silently.
- * CAMD_OPT_PHASES: which part of the work a camd_sgbm_compute call queues -- 1 = the matching-cost volume only,
- * 2 = aggregation, winner-take-all and post-filters only (on the volume an earlier phase-1 call of the same handle
- * built), 3 (default) = both.  For callers that run the VALU-bound cost kernel and the HBM-bound aggregation passes of
- * consecutive batches on two streams (e.g. two camd_stream_create_cu_mask partitions of the chip); ordering the two
- * calls of a batch (an event) is the caller's business. */
+ * Either way a result that differs from OpenCV's is never handed back silently. */
 int camd_sgbm_set_option(camd_sgbm* h, int option, int value);
 /* synchronises `stream` and reports whether a device-side bounded wait of the last computes timed out, or a pair
  * was refused (CAMD_OPT_EXACT).  Without this call neither can pass unnoticed: the affected disparities are written as

@@ -15,10 +15,20 @@ from calibrating_amd.parallel_pairs import owner_of, shard_range
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "calibrating_amd.h")).read()
+def _header_symbols(name="calibrating_amd.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(camd_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+def _exported_symbols():
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or shutil.which("llvm-nm")
+    if nm is None:
+        pytest.skip("no nm on this machine")
+    out = subprocess.run([nm, "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    return sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("camd_")})
 
 
 def test_library_exports_every_header_symbol():
@@ -27,10 +37,26 @@ def test_library_exports_every_header_symbol():
     lib = _native.lib()
     for s in syms:
         assert hasattr(lib, s), "libcalibrating_amd.so does not export %s" % s
-    # and the binding table covers the whole header
-    assert set(syms) == set(_native.SIGNATURES)
+    # the binding table IS the public header: same names, nothing more, nothing less
+    assert sorted(syms) == sorted(_native.SIGNATURES)
+    # what has no counterpart in the reference's interface lives in the experimental header, bound separately
+    exp = _header_symbols("calibrating_amd_experimental.h")
+    assert sorted(exp) == sorted(_native.EXPERIMENTAL_SIGNATURES) and not set(exp) & set(syms)
+    # and the shared object exports exactly the two headers' C symbols
+    assert _exported_symbols() == sorted(syms + exp)
     assert lib.camd_version() >= 100
     assert lib.camd_sgbm_num_stages() > 0 and lib.camd_sgbm_stage_name(0)
+
+
+def test_the_product_does_not_call_the_experimental_entry_points():
+    """camd_stream_create_cu_mask / camd_stream_destroy / CAMD_OPT_PHASES are measurement hooks: no module of the
+    package may call them (tools/ and tests/ may)."""
+    pkg = os.path.join(ROOT, "calibrating_amd")
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py") and f != "_native.py":
+            src = open(os.path.join(pkg, f)).read()
+            assert "camd_stream_" not in src, f
+            assert not re.search(r"set_option\(\s*[\"']phases", src), f
 
 
 def test_fails_loudly_without_gpu():

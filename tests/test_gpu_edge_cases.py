@@ -273,10 +273,12 @@ def test_cu_mask_stream_and_split_phases_give_the_same_disparity(oracle):
         ev = streams[0].record_event()
     with torch.cuda.stream(streams[1]):           # ... aggregation and post on the other 160
         streams[1].wait_event(ev)
-        m.set_option("phases", 2)
+        m.set_option("phases", 2)             # (first aggregation pass)
+        m.compute(L, R, out=out)
+        m.set_option("phases", 4)             # (last pass, winner-take-all, post filters)
         m.compute(L, R, out=out)
     streams[1].synchronize()
-    m.set_option("phases", 3)
+    m.set_option("phases", 7)
     m.status()
     assert np.array_equal(out.cpu().numpy(), want)
     with pytest.raises(ValueError):
@@ -285,3 +287,30 @@ def test_cu_mask_stream_and_split_phases_give_the_same_disparity(oracle):
     torch.cuda.synchronize()
     for st in handles:
         _native.check(lib.camd_stream_destroy(st))
+
+
+def test_resident_launches_give_the_same_disparity(oracle):
+    """CAMD_OPT_RESIDENT (experimental header): the cost kernel and the row-parallel last pass as a fixed number of
+    persistent workgroups per CU that take their items by ticket -- the launch form of the co-residency experiment
+    (profiles/r06_resident.txt).  Same bits as the ordinary launches, for several batches through one handle."""
+    p = dict(minDisparity=0, numDisparities=128, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, uniquenessRatio=10)
+    pairs = [synthetic.rectified_pair(seed=40 + i, H=70, W=333, D=128, cn=3) for i in range(3)]
+    L = torch.stack([torch.from_numpy(a[0]) for a in pairs]).cuda()
+    R = torch.stack([torch.from_numpy(a[1]) for a in pairs]).cuda()
+    want = np.stack([oracle.sgbm_compute(*a, **p) for a in pairs])
+    m = ca.StereoSGBM_create(**p)
+    m.set_option("path", 2)
+    for value in (0x21, 0x31, 0x10, 0x02, 0):
+        m.set_option("resident", value)
+        for _ in range(2):
+            assert np.array_equal(m.compute(L, R).cpu().numpy(), want), hex(value)
+    m.status()
+    with pytest.raises(ValueError):
+        m.set_option("resident", 0x55)
+    # gray, block 3: the other instantiations
+    p1 = dict(p, blockSize=3, P1=72, P2=288)
+    g = synthetic.rectified_pair(seed=44, H=64, W=300, D=128, cn=1)
+    m1 = ca.StereoSGBM_create(**p1)
+    m1.set_option("path", 2)
+    m1.set_option("resident", 0x21)
+    assert np.array_equal(m1.compute(*g), oracle.sgbm_compute(*g, **p1))

@@ -68,7 +68,7 @@ def main():
 
     def run_two(streams, steps):
         for m in ms:
-            m.set_option("phases", 3)
+            m.set_option("phases", 7)
         for k in range(4):
             with torch.cuda.stream(streams[k & 1]):
                 ms[k & 1].compute(L, R, out=outs[k & 1])
@@ -94,7 +94,7 @@ def main():
                 ev_cost[i].record(sx)
             with torch.cuda.stream(sy):
                 sy.wait_event(ev_cost[i])
-                m.set_option("phases", 2)
+                m.set_option("phases", 6)
                 m.compute(L, R, out=outs[i])
                 ev_done[i].record(sy)
 
@@ -107,7 +107,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         for m in ms:
-            m.set_option("phases", 3)
+            m.set_option("phases", 7)
         return dt
 
     def same():

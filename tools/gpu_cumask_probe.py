@@ -40,7 +40,7 @@ for name, f in patterns.items():
     _native.check(lib.camd_stream_create_cu_mask(words, 8, ctypes.byref(st)))
     s = torch.cuda.ExternalStream(st.value, device=dev)
     row = {"cus": n}
-    for label, ph in (("cost_ms", 1), ("aggregation_ms", 2)):
+    for label, ph in (("cost_ms", 1), ("aggregation_ms", 6)):
         m.set_option("phases", ph)
         with torch.cuda.stream(s):
             m.compute(L, R, out=out)
@@ -50,7 +50,7 @@ for name, f in patterns.items():
                 m.compute(L, R, out=out)
             s.synchronize()
         row[label] = (time.perf_counter() - t0) / 3 * 1e3
-    m.set_option("phases", 3)
+    m.set_option("phases", 7)
     res[name] = row
     print("%-22s %3d CUs  cost %7.2f ms  aggregation %7.2f ms" % (name, n, row["cost_ms"], row["aggregation_ms"]), flush=True)
     torch.cuda.synchronize()

@@ -56,8 +56,39 @@ def loops_of(txt, names):
         yield name, seq, loops, meta
 
 
+def write_mix(listing, out_path, names):
+    """profiles/rNN_isa_valu_mix.json: per kernel, the share of the main loop's VALU instructions in each issue class --
+    what bench.py prices a kernel's SQ_INSTS_VALU with (roofline.kernels.*.valu_floor_ms)."""
+    import json
+    import subprocess
+    txt = open(listing).read().split("\n")
+    doc = {"source": "hipcc -O3 --offload-arch=gfx950 -S of calibrating_amd/csrc/sgbm.hip; largest loop of each kernel; "
+                     "classes and rates: tools/microtests/valu_rate.hip (plain 32-bit VOP1/VOP2 + v_bitop3 ~1.55 per cycle and "
+                     "CU, packed / DPP / SDWA / three-operand / min-max ~0.9)", "kernels": {}}
+    for name, seq, loops, meta in loops_of(txt, names):
+        if not loops:
+            continue
+        lo, hi = loops[0]
+        c = collections.Counter(classify(l.split()[0]) for l in seq[lo:hi + 1])
+        n = c["fast"] + c["slow"]
+        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+        dem = re.sub(r"^void ", "", dem.split("(")[0])
+        doc["kernels"][dem] = {"valu_in_loop": n, "fast_frac": c["fast"] / n, "slow_frac": c["slow"] / n,
+                               "vgprs": meta.get("NumVgprs"), "scratch_bytes": meta.get("ScratchSize")}
+    json.dump(doc, open(out_path, "w"), indent=1)
+    for k, v in doc["kernels"].items():
+        print("%-60s plain %.3f  packed-class %.3f  (%d VALU in the loop, %s VGPRs)" % (k, v["fast_frac"], v["slow_frac"],
+                                                                                      v["valu_in_loop"], v["vgprs"]))
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if "--mix" in args:  # isa_cost.py listing.s --mix out.json name_substring...
+        k = args.index("--mix")
+        out = args[k + 1]
+        del args[k:k + 2]
+        write_mix(args[0], out, args[1:])
+        sys.exit(0)
     rows = 1
     if "--rows" in args:
         k = args.index("--rows")
