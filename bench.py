@@ -779,8 +779,17 @@ def main():
         m2.set_profiling(True)
         m2.set_option("path", a.path)
         m2.set_option("cost", a.cost)
-        d2, _ = gpu_steps(m2, left, right, out, k2, 1)
+        d2, st2 = gpu_steps(m2, left, right, out, k2, 1)
         also["%s_%s_pairs_per_s" % ("rgb" if a.channels == 3 else "gray", other)] = nb * k2 / d2
+        # the other mode's kernels one by one (hipEvents inside the library), priced like roofline.kernels: algorithmic
+        # bytes per launch / launch duration against the HBM peak
+        _, V2 = algorithmic_bytes_per_pair(a.width, a.height, a.disparities, a.channels)
+        t2 = stage_table(V2, a.width * a.height, a.channels, other)
+        also[other] = {"pairs_per_s": nb * k2 / d2, "batches_in_flight": 1, "per_kernel": {
+            st: {"kernel": t2[st][0], "avg_ms_per_launch": ms / k2, "algorithmic_bytes_per_launch": float(t2[st][1] * nb),
+                 "achieved_GBs": t2[st][1] * nb / (ms / k2 * 1e-3) / 1e9,
+                 "frac": t2[st][1] * nb / (ms / k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            for st, ms in st2.items() if st in t2 and ms / k2 >= 0.02}}
         del m2
         if a.channels == 3:
             m3 = ca.StereoSGBM_create(**sgbm_params(a, channels=1))

@@ -362,6 +362,35 @@ __device__ __forceinline__ void st_regs(uint16_t* __restrict__ p, const uint32_t
         __builtin_memcpy(p, &t, sizeof(t));
     }
 }
+// streaming variants (global_load / global_store ... nt): the volumes are read and written once per pass.  Measured on the
+// band passes (CAMD_BAND_NT, tools/gpu_r6_nt.sh) -- see sgbm_band.hpp
+typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+template <int NR>
+__device__ __forceinline__ void ld_regs_nt(const uint16_t* __restrict__ p, uint32_t (&dst)[NR])
+{
+    if constexpr (NR % 4 == 0) {
+        const nt_u32x4* q = reinterpret_cast<const nt_u32x4*>(p);
+#pragma unroll
+        for (int v = 0; v < NR / 4; v++) {
+            const nt_u32x4 w = __builtin_nontemporal_load(q + v);
+            dst[4 * v] = w.x; dst[4 * v + 1] = w.y; dst[4 * v + 2] = w.z; dst[4 * v + 3] = w.w;
+        }
+    } else {
+        ld_regs<NR>(p, dst);
+    }
+}
+template <int NR>
+__device__ __forceinline__ void st_regs_nt(uint16_t* __restrict__ p, const uint32_t (&src)[NR])
+{
+    if constexpr (NR % 4 == 0) {
+        nt_u32x4* q = reinterpret_cast<nt_u32x4*>(p);
+#pragma unroll
+        for (int v = 0; v < NR / 4; v++)
+            __builtin_nontemporal_store(nt_u32x4{src[4 * v], src[4 * v + 1], src[4 * v + 2], src[4 * v + 3]}, q + v);
+    } else {
+        st_regs<NR>(p, src);
+    }
+}
 template <int NR> __device__ __forceinline__ uint32_t reg_or0(const uint32_t (&a)[NR], int i) { return i < NR ? a[i < NR ? i : 0] : 0u; }
 // LDS: slot v of lane `idx` lives at p[v * stride + idx] -- one PLANE per slot, so that consecutive lanes are 16 bytes
 // apart in every ds_read_b128 / ds_write_b128 (lane-major slots, p[idx * NQ + v], put the lanes 32 bytes apart at

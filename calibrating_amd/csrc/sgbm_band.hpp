@@ -51,6 +51,16 @@ namespace camd {
 #ifndef CAMD_BAND_HELPER_WAVE
 #define CAMD_BAND_HELPER_WAVE CAMD_BAND_COMPUTE_WAVES    // !MERGED: which wave of the workgroup is the helper (default: the last)
 #endif
+// Cache policy of the volume accesses (bit 0: the C / S loads carry `nt`, bit 1: the S stores too).  Every volume byte is
+// read once per pass; streamed past the L2's replacement order the first pass takes 15.1 instead of 15.3 ms and the
+// row-parallel last pass 11.6 instead of 12.2 per 64 pairs (profiles/r06_band_nt.txt, three A/B repetitions).  `nt` on the
+// S stores changes nothing (bit 1 off); `nt` on k_cost's 16-byte C stores defeats the L2's write combining: 72 ms.
+#ifndef CAMD_BAND_NT
+#define CAMD_BAND_NT 1
+#endif
+#ifndef CAMD_BAND_FLAG_DELAY
+#define CAMD_BAND_FLAG_DELAY 0                           // steps between a chunk's last column and its flag (0 = drain at once)
+#endif
 #ifndef CAMD_ROW_PERSIST_PRIO
 #define CAMD_ROW_PERSIST_PRIO 3                          // s_setprio of k_band_row_persist's waves (0 = leave it)
 #endif
@@ -348,7 +358,10 @@ __device__ __forceinline__ void band_body(const BandArgs& a, const Geom& g, cons
     const uint16_t* Crow = a.C + rowoff;
     uint16_t* Srow = a.S + rowoff;
     auto cell_off = [&](int xi) -> size_t { return (size_t)(a.sx > 0 ? xi : W1 - 1 - xi) * g.Dp; };
-    auto load_vec = [&](const uint16_t* p, uint32_t (&dst)[NR]) { ld_regs<NR>(p, dst); };
+    auto load_vec = [&](const uint16_t* p, uint32_t (&dst)[NR]) {
+        if (CAMD_BAND_NT & 1) ld_regs_nt<NR>(p, dst);
+        else ld_regs<NR>(p, dst);
+    };
     auto lds_vec = [&](const uint4* p, int idx, int stride, uint32_t (&dst)[NR]) { lds_ld_regs<NR>(p, idx, stride, dst); };
 
     // ---- edge buffers ------------------------------------------------------------------------------
@@ -574,7 +587,8 @@ __device__ __forceinline__ void band_body(const BandArgs& a, const Geom& g, cons
                 if (s[0] == 0x12345678u) st_regs<NR>(Srow + cell_off(xi), s);
 #else
                 if (MODE != 2 || a.write_S) {
-                    st_regs<NR>(Srow + cell_off(xi), s);
+                    if (CAMD_BAND_NT & 2) st_regs_nt<NR>(Srow + cell_off(xi), s);
+                    else st_regs<NR>(Srow + cell_off(xi), s);
                 }
 #endif
                 if (MODE == 2) band_wta_step<LANES, NR, TIE8, NTH>(s, dpk, wS, g, ctid, grp, li, t, true, cap_key, cap_nb);
@@ -610,12 +624,37 @@ __device__ __forceinline__ void band_body(const BandArgs& a, const Geom& g, cons
                                            __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(q + 1, (unsigned long long)dAo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+#if CAMD_BAND_FLAG_DELAY == 0
                     if ((xi % BAND_CHUNK) == BAND_CHUNK - 1 || xi == W1 - 1) {
                         // the write-through stores of the whole chunk must have landed before the flag is raised
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         if (li == 0)
                             __hip_atomic_store(Fout + xi / BAND_CHUNK, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+#else
+                    // The write-through stores of a whole chunk must have landed before its flag is raised.  Waiting for
+                    // them right behind the chunk's last store (s_waitcnt vmcnt(0)) also drains this wave's C / S prefetch
+                    // ring and the stores just issued: one full memory latency every BAND_CHUNK steps during which the
+                    // other six waves stand at the barrier.  The memory counter retires in order, so the flag of a chunk is
+                    // raised FLAG_DELAY steps after its last column instead, behind a COUNTED wait: every step the producer
+                    // group is active in issues at least OPS vector-memory operations in this wave (the C load, the S store
+                    // or load, the edge-record stores), so once all but the newest FLAG_DELAY * OPS have retired, everything
+                    // up to the chunk's last store has.  The last column of the row drains and raises what is left.
+                    constexpr int FLAG_DELAY = CAMD_BAND_FLAG_DELAY;
+                    constexpr int OPS = 3 * ((NR + 1) / 2) + 2 + 2;  // (lower bound: edge vectors + 2 delta stores + C + S)
+                    static_assert(FLAG_DELAY * OPS <= 63, "vmcnt is a 6-bit counter");
+                    if (xi == W1 - 1) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        // chunks whose delayed raise (at column 16 m + 15 + FLAG_DELAY) lies before this column are up
+                        const int up = W1 - 2 - FLAG_DELAY - (BAND_CHUNK - 1) >= 0 ? (W1 - 2 - FLAG_DELAY - (BAND_CHUNK - 1)) / BAND_CHUNK + 1 : 0;
+                        if (li < a.nchunks - up)
+                            __hip_atomic_store(Fout + up + li, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else if (xi >= FLAG_DELAY && ((xi - FLAG_DELAY) % BAND_CHUNK) == BAND_CHUNK - 1) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FLAG_DELAY * OPS) : "memory");
+                        if (li == 0)
+                            __hip_atomic_store(Fout + (xi - FLAG_DELAY) / BAND_CHUNK, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#endif
                 }
                 // LDS-only barrier (a __syncthreads() would drain the C/S prefetch ring)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

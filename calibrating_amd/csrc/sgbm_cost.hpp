@@ -61,6 +61,12 @@ static constexpr int COST_DL = 8;  // disparities per lane (the DL = 16 instanti
 #ifndef CAMD_COST_STAGE
 #define CAMD_COST_STAGE 1
 #endif
+// 1 (measurement build): the C stores carry `nt`.  A pixel's 256-byte disparity vector is written 16 bytes at a time by
+// 16 waves of two workgroups; streamed past the L2 those pieces reach HBM as partial lines: 72 instead of 16 ms
+// (profiles/r06_band_nt.txt).  The L2's write combining is what makes the "lanes = columns" store pattern affordable.
+#ifndef CAMD_COST_NT
+#define CAMD_COST_NT 0
+#endif
 // 1: RGB at blockSize <= 5 runs 16 disparities per lane (sgbm.hip: the launch); 2: gray too; 0: 8 everywhere
 #ifndef CAMD_COST_DL16
 #define CAMD_COST_DL16 0
@@ -474,7 +480,11 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
                     uint4* o = reinterpret_cast<uint4*>(outp + (size_t)y * W1 * g.Dp);
 #pragma unroll
                     for (int q = 0; q < NP / 4; q++) {
-                        o[q] = make_uint4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                        if (CAMD_COST_NT)
+                            __builtin_nontemporal_store(u32x4_t{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]},
+                                                        reinterpret_cast<u32x4_t*>(o) + q);
+                        else
+                            o[q] = make_uint4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
                         if (SAT) neg_min = pk_min_i16(pk_min_i16(neg_min, pk_min_i16(acc[4 * q], acc[4 * q + 1])),
                                                       pk_min_i16(acc[4 * q + 2], acc[4 * q + 3]));
                         if (!SAT && ovf_thresh >= 0)  // (uniform)

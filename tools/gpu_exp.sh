@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of library variants built by tools/build_dbg.sh: tools/gpu_exp.sh "<bench args>" name [name ...]
 ARGS=$1; shift
-run() { python bench.py --no-cpu-baseline --no-also --steps 20 --warmup 2 --in-flight 1 $ARGS "$@" 2>/dev/null | python -c "
+run() { python bench.py --no-cpu-baseline --no-also --no-pmc --steps 20 --warmup 2 --in-flight 1 $ARGS "$@" 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
