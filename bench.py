@@ -490,8 +490,11 @@ def config_c4(ca, synthetic, dev, nb=16, reps=3):
     return dict(workload="3840x2160 gray rectified pairs, numDisparities=256 blockSize=5 MODE_SGBM, %d pairs per call, "
                          "one batch at a time" % nb, pairs_per_s=rate, algorithmic_bytes_per_pair=b_alg,
                 achieved_GBs=b_alg * rate / 1e9, frac=b_alg * rate / 1e9 / HBM_PEAK_GBS, per_kernel=kernels,
-                note="a 4K pair is 78 bands deep: the first band pass is bound by the wavefront's critical path, not by "
-                     "throughput (12 pairs x 2 in flight or 8 x 3 give the same rate: profiles/r05_c4_batching.txt)")
+                note="throughput-bound at the same per-byte efficiency as the 1080p workload, not by the fill of its 78-band "
+                     "wavefront: 24 pairs per call, 12 x 2 or 8 x 3 in flight give the same rate (profiles/r05_c4_batching.txt). "
+                     "At 8 registers per lane (D = 256) the band passes fit ONE 7 + 1-wave workgroup per CU (167 VGPRs), which "
+                     "is what holds their fractions at 0.53 / 0.66; k_cost for gray writes its volume at ~2.9 TB/s, the rate "
+                     "at which 16-byte store pieces of 16 waves combine in the L2")
 
 
 def depth_path_stages(st, imgs1, imgs2, W, H, D, cn, reps=5):

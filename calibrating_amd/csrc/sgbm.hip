@@ -1186,11 +1186,20 @@ static int launch_exact(const camd_sgbm* h, int nvolumes, int16_t* dst, size_t s
     a.invalid = (g.minD - 1) * 16;
     CAMD_HIP(hipMemsetAsync(h->xbar, 0, 4, st));
     const size_t lds = align_up((size_t)g.W * 6, 16);
-    const dim3 grid(h->num_cus > 0 ? h->num_cus : 256);  // one workgroup per compute unit: all resident at once
+    // One workgroup per compute unit and a hand-rolled grid barrier between the phases: the workgroups must all be
+    // resident at once.  A cooperative launch makes the runtime check that (it refuses a grid that cannot be); where it is
+    // refused or unsupported the plain launch runs with the barrier's bounded wait as the safety net (error bit 2).
+    const dim3 grid(h->num_cus > 0 ? h->num_cus : 256);
+    Geom gg = g;
+    void* kargs[] = {(void*)&a, (void*)&gg, (void*)&sd};
 #define CAMD_XALL(LN, NRR)                                                                                          \
     do {                                                                                                            \
-        if (way3) hipLaunchKernelGGL((k_exact_all<LN, NRR, true>), grid, dim3(256), lds, st, a, g, sd);             \
-        else hipLaunchKernelGGL((k_exact_all<LN, NRR, false>), grid, dim3(256), lds, st, a, g, sd);                 \
+        const void* fn = way3 ? (const void*)k_exact_all<LN, NRR, true> : (const void*)k_exact_all<LN, NRR, false>; \
+        if (hipLaunchCooperativeKernel(fn, grid, dim3(256), kargs, lds, st) != hipSuccess) {                        \
+            (void)hipGetLastError();                                                                                \
+            if (way3) hipLaunchKernelGGL((k_exact_all<LN, NRR, true>), grid, dim3(256), lds, st, a, g, sd);         \
+            else hipLaunchKernelGGL((k_exact_all<LN, NRR, false>), grid, dim3(256), lds, st, a, g, sd);             \
+        }                                                                                                           \
     } while (0)
     CAMD_FOR_SHAPE(g, CAMD_XALL);
 #undef CAMD_XALL
@@ -1363,6 +1372,11 @@ static const char* device_error_text(uint32_t e)
         "a band-wavefront pass timed out waiting for its upstream band (the disparities of that call were written as "
         "invalid) AND a cost volume left the int16 regime of the aggregation kernels with no workspace for the exact "
         "path (that pair was written as invalid)";
+    static const char* kBarrier =
+        "the exact int path's grid barrier timed out (its workgroups were not all resident at once -- e.g. on a stream "
+        "restricted to few compute units while other kernels held them); the disparities of the flagged pairs were written "
+        "as invalid";
+    if (e & 4u) return kBarrier;
     return (e & 3u) == 3u ? kBoth : ((e & 2u) ? kRefused : kTimeout);
 }
 

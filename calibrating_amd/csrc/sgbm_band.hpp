@@ -301,7 +301,7 @@ __device__ __forceinline__ void band_body(const BandArgs& a, const Geom& g, cons
     constexpr int EVEC = 6 * NQ;     // u64 per lane per column: V (2NQ), Dg (2NQ), A (2NQ)
     constexpr int CPB = 64 / LANES;  // columns the helper wave fetches per batch
     constexpr int RING = FULL ? BAND_RING : BAND_RING_ROWS;
-    constexpr int SK = FULL ? 2 : 0;
+    constexpr int SK = FULL ? 2 : 0;  // (staggering the rows of the row-parallel pass by 1 or 3 columns: no faster, profiles/r06_row_skew.txt)
     constexpr int XN = FULL ? BAND_THREADS * NQ : 1, EN = FULL ? 64 * NQ : 1;
 
     __shared__ uint4 xV[2][XN];

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_exact_all(ExactArgs a, Geom g, ScanDirs
             while (!dead && __hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > EXACT_SPIN_LIMIT) {
-                    atomicOr(a.err, 1u);
+                    atomicOr(a.err, 4u);  // bit 2: this grid barrier (bit 0 is a band pass's upstream wait)
                     dead = true;
                 }
             }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_exact_all(ExactArgs a, Geom g, ScanDirs
         grid_sync();
     }
     // a barrier that gave up: never hand back what may have been computed from half-written volumes
-    if (any && (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) {
+    if (any && (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u)) {
         for (int vp = 0; vp < a.nvol; vp++) {
             if (!a.neg[vp]) continue;
             for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.dst_n; i += (size_t)gridDim.x * 256)

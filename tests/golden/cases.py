@@ -304,6 +304,24 @@ def load(producer, stage):
 
 # tolerance of a stage against a cv2-made file, as SURVEY.md section 8(d) states it: SGBM / post filters / tables are
 # bit-exact, remaps and resizes of u8 may differ by 1 LSB (table rounding U8/U15), float maps / resizes by float eps
+# What a cv2 fixture of each stage decides, and which switch moves the oracle AND the HIP path together if it disagrees
+# (oracle.set_switches / oracle_set_switches on the CPU side, camd_sgbm_set_option /
+# camd_set_global_option on the GPU side).  Quoted by the skip and failure messages of the golden tests and by
+# tools/export_cv2_golden.py, so that whoever first runs them with a real cv2 knows where to look.
+WHAT_IT_PINS = {
+    "sgbm": "BASELINE metric max |disparity - cv2.SGBM|; decides U1-U6, U10-U12, U14 (no switch: restated semantics), "
+            "U7 (oracle cost_saturate / CAMD_OPT_SATURATE), U11 (oracle bt_border_raw_tab0), U16-U20 MODE_SGBM_3WAY "
+            "(oracle way3_stripes, way3_simd_lanes / CAMD_OPT_3WAY_SIMD_LANES)",
+    "remap": "cv2.remap INTER_LANCZOS4 / INTER_NEAREST; decides U8 / U15 (oracle lanczos_fix_group_lo / "
+             "CAMD_GOPT_LANCZOS_FIX_GROUP_LO) and U13 (round-half-to-even of the nearest remap)",
+    "maps": "cv2.initUndistortRectifyMap (float64 inside, CV_32FC1 out)",
+    "undistort": "cv2.undistort = fixed-point bilinear remap through its internal CV_16SC2 maps",
+    "resize": "cv2.resize INTER_LINEAR as boxx.resize calls it; decides U9",
+    "post": "cv2.medianBlur(3) on int16 and cv2.filterSpeckles; decides U5",
+    "rodrigues": "cv2.Rodrigues (vector -> matrix)",
+}
+
+
 def tolerance(stage, key, dtype):
     if stage in ("sgbm", "post"):
         return 0

@@ -38,12 +38,14 @@ def test_fixture_inputs_match_the_catalogue():
 def test_oracle_matches_cv2_fixtures(oracle, stage):
     data = cases.load("cv2", stage)
     if data is None:
-        pytest.skip("tests/golden/cv2_%s.npz absent: run tools/export_cv2_golden.py where cv2 is installed" % stage)
+        pytest.skip("tests/golden/cv2_%s.npz absent: run `python tools/export_cv2_golden.py` where cv2 is installed and "
+                    "commit what it writes; it pins: %s" % (stage, cases.WHAT_IT_PINS[stage]))
     for name, ins, outs in data:
         got = cases.run("oracle", dict(name=name, stage=stage, inputs=ins))
         for k, want in outs.items():
             d = np.abs(np.asarray(got[k], np.float64) - np.asarray(want, np.float64)).max() if want.size else 0.0
-            assert d <= cases.tolerance(stage, k, want.dtype), "%s/%s/%s: max |oracle - cv2| = %g" % (stage, name, k, d)
+            assert d <= cases.tolerance(stage, k, want.dtype), "%s/%s/%s: max |oracle - cv2| = %g.  %s" % (
+                stage, name, k, d, cases.WHAT_IT_PINS[stage])
 
 
 def test_export_tool_plumbing(tmp_path, monkeypatch, oracle):

@@ -17,7 +17,8 @@ import cases  # noqa: E402
 def _check(producer, stage, exact):
     data = cases.load(producer, stage)
     if data is None:
-        pytest.skip("tests/golden/%s_%s.npz absent" % (producer, stage))
+        pytest.skip("tests/golden/%s_%s.npz absent -- run `python tools/export_cv2_golden.py` where cv2 is installed and "
+                    "commit what it writes; it pins: %s" % (producer, stage, cases.WHAT_IT_PINS[stage]))
     for name, ins, outs in data:
         got = cases.run("gpu", dict(name=name, stage=stage, inputs=ins))
         for k, want in outs.items():
@@ -27,7 +28,9 @@ def _check(producer, stage, exact):
             tol = 0 if exact else cases.tolerance(stage, k, want.dtype)
             if stage in ("maps", "rodrigues", "resize") and not np.issubdtype(want.dtype, np.integer):
                 tol = max(tol, 1e-4 if stage != "rodrigues" else 1e-12)  # float stages: SURVEY 8(d) tolerances
-            assert d <= tol, "%s/%s/%s: max |gpu - %s| = %g" % (stage, name, k, producer, d)
+            # (a committed fixture that differs FAILS -- it never skips; the message names the switch to look at)
+            assert d <= tol, "%s/%s/%s: max |gpu - %s| = %g (tolerance %g).  %s" % (
+                stage, name, k, producer, d, tol, cases.WHAT_IT_PINS[stage] if producer == "cv2" else "")
 
 
 @pytest.mark.parametrize("stage", cases.STAGES)

@@ -30,8 +30,10 @@ def main():
         sys.exit("export_cv2_golden.py needs OpenCV (pip install opencv-contrib-python>=4.7.0.72, the reference's pin)")
     import cases
     print("cv2 %s, %d threads" % (cv2.__version__, cv2.getNumThreads()))
+    written = []
     for p in cases.write("cv2"):
-        print("wrote %s (%d KB)" % (os.path.relpath(p, ROOT), os.path.getsize(p) // 1024))
+        written.append(os.path.relpath(p, ROOT))
+        print("wrote %s (%d KB)" % (written[-1], os.path.getsize(p) // 1024))
     # report: the repo's oracle against what was just written
     try:
         worst = {}
@@ -45,8 +47,15 @@ def main():
                     print("  %s %-9s %-32s %-8s max|oracle - cv2| = %g (tolerance %g)" % (flag, st, name, k, d, tol))
                     worst[st] = max(worst.get(st, 0.0), d)
         print("worst per stage:", worst)
+        for st in cases.STAGES:
+            if worst.get(st, 0.0) > 0:
+                print("  %-9s differs somewhere -> %s" % (st, cases.WHAT_IT_PINS[st]))
     except Exception as e:  # the export itself succeeded; the comparison needs gcc + this repo's oracle
         print("oracle comparison skipped:", e)
+    print("\nCommit exactly these files (data only: inputs and what cv2 %s returned):\n  git add %s\n"
+          "then `python -m pytest tests -m 'not gpu'` checks the CPU oracle against them (tests/test_golden_cpu.py) and\n"
+          "`python -m pytest tests -m gpu` the HIP kernels (tests/test_gpu_golden.py; the sgbm stage IS the BASELINE metric\n"
+          "max |disparity - cv2.SGBM|).  A fixture that differs fails, it does not skip." % (cv2.__version__, " ".join(written)))
 
 
 if __name__ == "__main__":

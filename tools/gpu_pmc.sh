@@ -12,7 +12,7 @@ for CTRS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
             "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVES" \
             "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 900 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/raw$i -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --in-flight 1 --batch $BATCH --no-also --no-cpu-baseline "$@" > $OUT/log$i.txt 2>&1
+  timeout 900 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/raw$i -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --in-flight 1 --batch $BATCH --no-also --no-cpu-baseline --no-pmc "$@" > $OUT/log$i.txt 2>&1
   find $OUT/raw$i -name "*counter_collection*" -exec cp {} $OUT/counters$i.csv \;
 done
 python - <<PY

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BATCH=${BATCH:-16}
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/raw_$C -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --in-flight 1 --batch $BATCH --no-also --no-cpu-baseline "$@" > $OUT/log_$C.txt 2>&1
+  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/raw_$C -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --in-flight 1 --batch $BATCH --no-also --no-cpu-baseline --no-pmc "$@" > $OUT/log_$C.txt 2>&1
   find $OUT/raw_$C -name "*counter_collection*" -exec cp {} $OUT/$C.csv \;
   rm -rf $OUT/raw_$C
 done

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --in-flight 1 --no-cpu-baseline "$@" > $OUT/bench_under_rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --in-flight 1 --no-cpu-baseline --no-pmc "$@" > $OUT/bench_under_rocprof.log 2>&1
 echo "rocprof exit: $?" >> $OUT/bench_under_rocprof.log
 find $OUT/raw -name "*kernel_stats*" -exec cp {} $OUT/ \;
 find $OUT/raw -name "*domain_stats*" -exec cp {} $OUT/ \;
