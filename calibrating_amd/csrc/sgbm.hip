@@ -363,7 +363,7 @@ __device__ __forceinline__ void st_regs(uint16_t* __restrict__ p, const uint32_t
     }
 }
 // streaming variants (global_load / global_store ... nt): the volumes are read and written once per pass.  Measured on the
-// band passes (CAMD_BAND_NT, tools/gpu_r6_nt.sh) -- see sgbm_band.hpp
+// band passes (CAMD_BAND_NT, tools/history/gpu_r6_nt.sh) -- see sgbm_band.hpp
 typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
 template <int NR>
 __device__ __forceinline__ void ld_regs_nt(const uint16_t* __restrict__ p, uint32_t (&dst)[NR])
@@ -814,6 +814,7 @@ struct camd_sgbm {
     int max_batch;
     size_t vol_elems;     // per pair, int16 elements of one volume
     uint16_t *C, *S;      // S doubles as the hsum buffer before aggregation
+    uint16_t* S_alloc;    // what hipMalloc returned for S (S = S_alloc + CAMD_S_OFFSET bytes, a measurement hook: 0)
     int16_t* raw;         // [max_batch][H][W] disparity before median
     void* speckle_ws;
     bool speckle_clean;   // every parent entry of speckle_ws is -1 (post.hip keeps it so from call to call)
@@ -1291,7 +1292,14 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
             if (e == hipSuccess) e = hipStreamSynchronize(fs);
             if (fs) (void)hipStreamDestroy(fs);
         }
-        if (e == hipSuccess) e = hipMalloc((void**)&h->S, nvol * h->vol_elems * 2);
+        {
+            // measurement hook: S shifted against C by CAMD_S_OFFSET bytes (a multiple of 256), to see whether the C read
+            // and S write streams of a pass, which touch the same pixel offsets at the same time, collide in HBM channels
+            const char* so = getenv("CAMD_S_OFFSET");
+            const size_t off = so ? (size_t)atol(so) / 256 * 256 : 0;
+            if (e == hipSuccess) e = hipMalloc((void**)&h->S_alloc, nvol * h->vol_elems * 2 + off);
+            h->S = h->S_alloc ? h->S_alloc + off / 2 : nullptr;
+        }
         if (e == hipSuccess && way3) e = hipMalloc((void**)&h->rawv, nvol * align_up((size_t)vrows * width * 2, 256));
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->raw, (size_t)max_batch * raw_e * 2);
@@ -1385,7 +1393,7 @@ int camd_sgbm_destroy(camd_sgbm* h)
     if (!h) return CAMD_OK;
     if (h->ev_ok)
         for (int i = 0; i <= ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
-    (void)hipFree(h->C); (void)hipFree(h->S);
+    (void)hipFree(h->C); (void)hipFree(h->S_alloc);
     (void)hipFree(h->raw); (void)hipFree(h->rawv); (void)hipFree(h->speckle_ws); (void)hipFree(h->cost_ovf);
     (void)hipFree(h->E); (void)hipFree(h->flags); (void)hipFree(h->ticket); (void)hipFree(h->keys);
     (void)hipFree(h->d1); (void)hipFree(h->Smulti); (void)hipFree(h->Lx);

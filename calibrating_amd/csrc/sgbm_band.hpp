@@ -218,14 +218,9 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[NR], const uin
     // plane v of the parked vectors: [group][LANES + pad] uint4 (see WtaPad); WS_PLANE uint4 per plane
     constexpr int GST = LANES + WtaPad<LANES>::Q, WS_PLANE = (NTH / LANES) * GST;
     lds_st_regs<NR>(wS, grp * GST + li, WS_PLANE, s);
-    // (2) uniqueness: S[d]*(100-u) < minS*100 for some |d-best| > 1
-    //     <=>  min over those d of S[d]  <=  T = floor((minS*100 - 1) / (100-u)); the division by the launch
-    //     constant 100-u is a multiply-high by floor(2^32/(100-u)) + 1, exact for numerators < 2^32/100
-    int T = -1;
-    if (minS > 0) {
-        const uint32_t n = (uint32_t)(minS * 100 - 1);
-        T = (int)(g.uniq_magic ? __umulhi(n, g.uniq_magic) : n);
-    }
+    // (2) uniqueness: not unique iff S[d]*(100-u) < minS*100 for some |d-best| > 1, i.e. iff that holds for the smallest
+    //     such S[d] (100-u >= 1 on this path): two 24-bit multiplies of group-uniform values, no division
+    //     (S <= 0xffff and 100-u <= 100: both products stay below 2^24)
     // the window best-1 .. best+1 is masked out in packed arithmetic: diff = d - (best-1) (mod 2^16) is 0, 1, 2
     // exactly there, w = sat(3 - diff) is non-zero exactly there, and sat(w * 0xFFFF + S) = 0xFFFF
     const uint32_t bm1 = dup16((uint32_t)(best - 1));
@@ -236,7 +231,8 @@ __device__ __forceinline__ void band_wta_step(const uint32_t (&s)[NR], const uin
         far = pk_min_u16(far, pk_mad_sat_u16(w, 0xffffffffu, s[k]));
     }
     const int minfar = (int)(group_min_dup16<LANES>(far) & 0xffffu);
-    const bool ok = act && minS < MAX_COST && minfar > T;
+    const uint32_t uq = g.uniq <= 98 ? (uint32_t)(100 - g.uniq) : 1u;  // (uniq_magic == 0 stood for a divisor of 1)
+    const bool ok = act && minS < MAX_COST && __umul24((uint32_t)minfar, uq) >= __umul24((uint32_t)minS, 100u);
     // (3) neighbours for the sub-pixel parabola (same address in every lane of the group: an LDS broadcast)
     const uint16_t* gs = reinterpret_cast<const uint16_t*>(wS + grp * GST);
     // disparity d sits in lane d / (2 NR), element w = d % (2 NR): plane w / 8, u16 (lane * 8 + w % 8) of the group's row

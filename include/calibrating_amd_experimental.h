@@ -2,7 +2,7 @@
  * calibrating_amd_experimental.h -- entry points of libcalibrating_amd.so that have NO counterpart in the reference's
  * interface and are on no default path: the measurement hooks of the overlap / partitioning experiments (DESIGN.md
  * section 4, profiles/r05_cumask*.json, profiles/r06_pipeline.json, profiles/r06_corun.json -- measured at no gain).
- * Nothing in calibrating_amd/ (the product) calls them; tools/gpu_cumask*.py, tools/gpu_r6_*.py and one parity test
+ * Nothing in calibrating_amd/ (the product) calls them; tools/history/gpu_cumask*.py, tools/gpu_r6_*.py and one parity test
  * do.  They may change or go away between rounds.
  */
 #ifndef CALIBRATING_AMD_EXPERIMENTAL_H
@@ -16,7 +16,7 @@ extern "C" {
 
 /* A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): bit i of cu_mask[i / 32]
  * enables CU i in the driver's enumeration, which walks the XCDs first -- bit 0 = XCD 0's first CU, bit 1 = XCD 1's,
- * ... -- so the first N bits are N / 8 CUs of every XCD (measured: tools/gpu_cumask_probe.py).  An XCD whose share of
+ * ... -- so the first N bits are N / 8 CUs of every XCD (measured: tools/history/gpu_cumask_probe.py).  An XCD whose share of
  * the mask is empty is left unrestricted, not disabled, and workgroups are dealt to the XCDs in equal shares: give
  * every XCD the same number of CUs, a multiple of its four shader engines (N a multiple of 32).  For spatial partitioning of concurrent work (one partition
  * for a VALU-bound kernel, the rest for an HBM-bound one).  The reference has no counterpart (single-threaded host

@@ -3,7 +3,7 @@
 aggregation passes (band passes: latency / HBM-bound) of one 64-pair batch on streams masked with different bit patterns
 of equal population.  -> gpurun_out/r05_cumask_probe.json"""
 import ctypes, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import calibrating_amd as ca
