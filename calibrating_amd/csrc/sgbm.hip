@@ -814,7 +814,6 @@ struct camd_sgbm {
     int max_batch;
     size_t vol_elems;     // per pair, int16 elements of one volume
     uint16_t *C, *S;      // S doubles as the hsum buffer before aggregation
-    uint16_t* S_alloc;    // what hipMalloc returned for S (S = S_alloc + CAMD_S_OFFSET bytes, a measurement hook: 0)
     int16_t* raw;         // [max_batch][H][W] disparity before median
     void* speckle_ws;
     bool speckle_clean;   // every parent entry of speckle_ws is -1 (post.hip keeps it so from call to call)
@@ -1292,14 +1291,9 @@ int camd_sgbm_create(const camd_sgbm_params* p, int width, int height, int chann
             if (e == hipSuccess) e = hipStreamSynchronize(fs);
             if (fs) (void)hipStreamDestroy(fs);
         }
-        {
-            // measurement hook: S shifted against C by CAMD_S_OFFSET bytes (a multiple of 256), to see whether the C read
-            // and S write streams of a pass, which touch the same pixel offsets at the same time, collide in HBM channels
-            const char* so = getenv("CAMD_S_OFFSET");
-            const size_t off = so ? (size_t)atol(so) / 256 * 256 : 0;
-            if (e == hipSuccess) e = hipMalloc((void**)&h->S_alloc, nvol * h->vol_elems * 2 + off);
-            h->S = h->S_alloc ? h->S_alloc + off / 2 : nullptr;
-        }
+        // (S shifted against C by 256 B ... 1 MB so that the two streams of a pass do not touch the same offsets at the same
+        // time: no difference, profiles/r06_s_offset.txt)
+        if (e == hipSuccess) e = hipMalloc((void**)&h->S, nvol * h->vol_elems * 2);
         if (e == hipSuccess && way3) e = hipMalloc((void**)&h->rawv, nvol * align_up((size_t)vrows * width * 2, 256));
     }
     if (e == hipSuccess) e = hipMalloc((void**)&h->raw, (size_t)max_batch * raw_e * 2);
@@ -1393,7 +1387,7 @@ int camd_sgbm_destroy(camd_sgbm* h)
     if (!h) return CAMD_OK;
     if (h->ev_ok)
         for (int i = 0; i <= ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
-    (void)hipFree(h->C); (void)hipFree(h->S_alloc);
+    (void)hipFree(h->C); (void)hipFree(h->S);
     (void)hipFree(h->raw); (void)hipFree(h->rawv); (void)hipFree(h->speckle_ws); (void)hipFree(h->cost_ovf);
     (void)hipFree(h->E); (void)hipFree(h->flags); (void)hipFree(h->ticket); (void)hipFree(h->keys);
     (void)hipFree(h->d1); (void)hipFree(h->Smulti); (void)hipFree(h->Lx);
