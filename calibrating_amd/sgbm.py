@@ -224,6 +224,10 @@ class StereoSGBM:
                 self._handle, left_t.data_ptr(), right_t.data_ptr(), w * cn, h * w * cn, out.data_ptr(),
                 w * 2, h * w * 2, n, _native.current_stream())
             _native.check(rc, "StereoSGBM.compute")
+        if not self._options.get(6, 7) & 4:
+            # (measurement hook 'phases' without the last part: nothing was written to `out`; hand back nothing rather than
+            # an uninitialised buffer -- or, for ndarray input, a host copy of one)
+            return None
         res = out.view(n, h, w) if batched else out.view(h, w)
         if is_np:
             res = hostio.to_host(res)
