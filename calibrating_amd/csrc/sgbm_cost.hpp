@@ -61,6 +61,16 @@ static constexpr int COST_DL = 8;  // disparities per lane (the DL = 16 instanti
 #ifndef CAMD_COST_STAGE
 #define CAMD_COST_STAGE 1
 #endif
+// How C leaves the kernel.  A pixel's disparity vector (256 B at D = 128) is produced 16 bytes at a time by the waves of
+// one or two workgroups; stored straight from the registers, every wave's store instruction touches 64 different lines
+// with 16 bytes each and the L2 has to combine 8 or 16 such pieces per line -- for gray, whose arithmetic is a third of
+// RGB's, that is what bounds the kernel (V written at 3.0 TB/s, 0.7 partial-line writes per clock and L2 channel).
+// With the bit set (bit 0 gray, bit 1 RGB) a row's 64 x NW pieces go through a double-buffered LDS tile instead
+// (written behind the row's arithmetic, read back after the row's barrier) and every wave stores whole runs of
+// NW x 16 contiguous bytes per pixel: the same number of store instructions, 1/NW of the L2 write transactions.
+#ifndef CAMD_COST_TSTORE
+#define CAMD_COST_TSTORE 1
+#endif
 // 1 (measurement build): the C stores carry `nt`.  A pixel's 256-byte disparity vector is written 16 bytes at a time by
 // 16 waves of two workgroups; streamed past the L2 those pieces reach HBM as partial lines: 72 instead of 16 ms
 // (profiles/r06_band_nt.txt).  The L2's write combining is what makes the "lanes = columns" store pattern affordable.
@@ -142,11 +152,15 @@ struct CostRanges {
     int start[4], rows[4];
 };
 
+// C leaves the kernel through LDS (CAMD_COST_TSTORE bit 0: gray, bit 1: RGB) when the waves of the workgroup divide the
+// strip's 64 columns: see the store in cost_body
+constexpr bool cost_tstore(int cn) { return (CAMD_COST_TSTORE & (cn == 1 ? 1 : 2)) != 0; }
+static inline bool cost_tstore_shape(int cn, int nwaves, int dl) { return cost_tstore(cn) && dl == COST_DL && 64 % nwaves == 0; }
 static inline size_t cost_lds_bytes(int cn, int nwaves, int dl = COST_DL)
 {
     const int es = cn == 1 ? 4 : 12, dw = nwaves * dl;
     const int nr = 64 + dw - 1, nl = 64;
-    return (size_t)2 * (nr + nl) * es * 4;
+    return (size_t)2 * (nr + nl) * es * 4 + (cost_tstore_shape(cn, nwaves, dl) ? (size_t)2 * 64 * (nwaves + 1) * 16 : 0);
 }
 
 // Only one dword of an entry's third quad is used; left alone the compiler narrows that read to ds_read_b32, whose 32
@@ -378,6 +392,23 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
     const int win_back = ((lane - K) & 63) << 2;
     const bool win_live = lane >= K;
     const uint32_t p2 = dup16((uint32_t)g.P2);
+    // the output tile (see CAMD_COST_TSTORE): [2][64 columns][NW + 1] quads behind the entry buffers; this lane writes
+    // quad (lane, w) and later stores the quad (column tpx, piece tpc) -- NW consecutive lanes = one column's NW pieces
+    // (uniform; the launch sized the LDS the same way.  Not for a disparity block with padding: its all-padding waves have
+    // left, and with them the columns they would flush)
+    const bool tstore = cost_tstore(CN) && DL == COST_DL && 64 % NW == 0 && db + DW <= g.D;
+    const int TP = NW + 1;
+    uint4* const Tbuf = Ebuf + 2 * esz;
+    const int tpx = w * (64 / NW) + lane / NW, tpc = lane % NW;
+    const int txo = xo0 + tpx - (K - 1);
+    const bool twriter = tpx >= K - 1 && txo < W1 && db + tpc * DL < g.Dp;
+    uint16_t* const toutp = Cout + (size_t)vpair * vol_stride + (size_t)(twriter ? txo : 0) * g.Dp + db + tpc * DL;
+    auto flush_row = [&](int r) {  // row step r's tile -> C (after the barrier that ended step r)
+        if (twriter) {
+            const uint4 v = Tbuf[((r & 1) * 64 + tpx) * TP + tpc];
+            *reinterpret_cast<uint4*>(toutp + (size_t)(y0 + r - (K - 1)) * W1 * g.Dp) = v;
+        }
+    };
     uint32_t acc[NP], ring[K][NP];
 #pragma unroll
     for (int k = 0; k < NP; k++) acc[k] = p2;
@@ -391,7 +422,7 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
         for (int u = 0; u < K; u++) {
             const int r = r0 + u;
             if (r < nsteps) {  // uniform
-
+                if (tstore && r >= K) flush_row(r - 1);
                 const uint4* E4 = Ebuf + (r & 1) * esz;
                 uint32_t U[CN], U0[CN], U1[CN];
                 {
@@ -475,12 +506,14 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
                         acc[k] = NOCARRY ? acc[k] + T - old : pk_sub_u16(pk_add_u16(acc[k], T), old);
                     }
                 }
+                if (tstore && r >= K - 1) Tbuf[((r & 1) * 64 + lane) * TP + w] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
                 if (r >= K - 1 && writer) {
                     const int y = y0 + r - (K - 1);
                     uint4* o = reinterpret_cast<uint4*>(outp + (size_t)y * W1 * g.Dp);
 #pragma unroll
                     for (int q = 0; q < NP / 4; q++) {
-                        if (CAMD_COST_NT)
+                        if (tstore) {
+                        } else if (CAMD_COST_NT)
                             __builtin_nontemporal_store(u32x4_t{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]},
                                                         reinterpret_cast<u32x4_t*>(o) + q);
                         else
@@ -504,6 +537,7 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
             }
         }
     }
+    if (tstore) flush_row(nsteps - 1);  // (the last step's barrier is behind us)
     if (!SAT && ovf_thresh >= 0 && (int)max(ovf_max & 0xffffu, ovf_max >> 16) > ovf_thresh) atomicOr(ovf + vpair, 1u);
     if (SAT && neg && min((int)(int16_t)(neg_min & 0xffffu), (int)(int16_t)(neg_min >> 16)) < g.P2) atomicOr(neg + vpair, 1u);
 }
