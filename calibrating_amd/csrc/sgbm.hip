@@ -391,6 +391,17 @@ __device__ __forceinline__ void st_regs_nt(uint16_t* __restrict__ p, const uint3
         st_regs<NR>(p, src);
     }
 }
+// The line-scan kernels and k_wta (the latency path) with `nt` loads: CAMD_SCAN_NT 1.  Measured no faster, rather slower
+// (one 1080p pair 1.79-1.88 -> 1.89-1.90 ms; MODE_HH 2.59-2.64 -> 2.70-2.91): there the five or eight direction scans of
+// ONE pair read the same C concurrently, and the L2 / MALL reuse that `nt` gives up is worth having.  Off.
+#ifndef CAMD_SCAN_NT
+#define CAMD_SCAN_NT 0
+#endif
+#if CAMD_SCAN_NT
+#define CAMD_SCAN_LD(p, dst) ld_regs_nt<NR>(p, dst)
+#else
+#define CAMD_SCAN_LD(p, dst) ld_regs<NR>(p, dst)
+#endif
 template <int NR> __device__ __forceinline__ uint32_t reg_or0(const uint32_t (&a)[NR], int i) { return i < NR ? a[i < NR ? i : 0] : 0u; }
 // LDS: slot v of lane `idx` lives at p[v * stride + idx] -- one PLANE per slot, so that consecutive lanes are 16 bytes
 // apart in every ds_read_b128 / ds_write_b128 (lane-major slots, p[idx * NQ + v], put the lanes 32 bytes apart at
@@ -487,8 +498,8 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
 #pragma unroll
     for (int u = 0; u < PF - 1; u++) {
         const ptrdiff_t o = (ptrdiff_t)min(u, len - 1) * step;
-        ld_regs<NR>(cp + o, cr[u]);
-        if (!FIRST) ld_regs<NR>(sp + o, sr[u]);
+        CAMD_SCAN_LD(cp + o, cr[u]);
+        if (!FIRST) CAMD_SCAN_LD(sp + o, sr[u]);
     }
     for (int i0 = 0; i0 < len; i0 += PF) {
 #pragma unroll
@@ -496,8 +507,8 @@ __global__ __launch_bounds__(256) void k_scan(const uint16_t* __restrict__ Cv, u
             const int i = i0 + u;
             {
                 const ptrdiff_t o = (ptrdiff_t)min(i + PF - 1, len - 1) * step;
-                ld_regs<NR>(cp + o, cr[(u + PF - 1) % PF]);
-                if (!FIRST) ld_regs<NR>(sp + o, sr[(u + PF - 1) % PF]);
+                CAMD_SCAN_LD(cp + o, cr[(u + PF - 1) % PF]);
+                if (!FIRST) CAMD_SCAN_LD(sp + o, sr[(u + PF - 1) % PF]);
             }
             if (i < len) {
                 const uint32_t(&c)[NR] = cr[u];
@@ -587,11 +598,11 @@ __device__ __forceinline__ void wta_row(const uint16_t* __restrict__ Sv, int16_t
     for (int x = grp; x < g.W1; x += GROUPS) {
         uint32_t s[NR];
         if (!EXACT) {
-            ld_regs<NR>(Srow + (size_t)x * g.Dp, s);
+            CAMD_SCAN_LD(Srow + (size_t)x * g.Dp, s);
             // concurrent-direction path: S = saturating sum of the per-direction volumes
             for (int dv = 1; dv < nvol; dv++) {
                 uint32_t q[NR];
-                ld_regs<NR>(Srow + (size_t)dv * dir_stride + (size_t)x * g.Dp, q);
+                CAMD_SCAN_LD(Srow + (size_t)dv * dir_stride + (size_t)x * g.Dp, q);
 #pragma unroll
                 for (int k = 0; k < NR; k++) s[k] = pk_addsat_i16(s[k], q[k]);
             }
