@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--mode", default="sgbm")
     ap.add_argument("--out", default="r06_pipeline.json")
+    ap.add_argument("--only-resident", action="store_true", help="run only the cost|last variant of each --resident value (for traces)")
     ap.add_argument("--resident", default="", help="comma list of hex values 0xAB: A cost / B last-pass workgroups per CU")
     a = ap.parse_args()
     import torch
@@ -104,8 +105,9 @@ def main():
 
     s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
     hi = torch.cuda.Stream(priority=-1)
-    report("serial", run_free([s0], a.steps), a.steps)
-    report("free2", run_free([s0, s1], a.steps), a.steps)
+    if not a.only_resident:
+        report("serial", run_free([s0], a.steps), a.steps)
+        report("free2", run_free([s0, s1], a.steps), a.steps)
     if not a.resident:
         for gate, name in (("first_done", "cost|last"), ("first_start", "cost|first"), (None, "cost|both")):
             report(name, run_pipe(s0, s1, gate, a.steps), a.steps)
@@ -116,9 +118,11 @@ def main():
         for m in ms:
             m.set_option("resident", r)
         tag = "resident %d:%d " % (r >> 4, r & 15)
-        report(tag + "serial", run_free([s0], a.steps), a.steps)
+        if not a.only_resident:
+            report(tag + "serial", run_free([s0], a.steps), a.steps)
         report(tag + "cost|last", run_pipe(s0, s1, "first_done", a.steps), a.steps)
-        report(tag + "cost|last agg-prio", run_pipe(s0, hi, "first_done", a.steps), a.steps)
+        if not a.only_resident:
+            report(tag + "cost|last agg-prio", run_pipe(s0, hi, "first_done", a.steps), a.steps)
         for m in ms:
             m.set_option("resident", 0)
     for m in ms:
