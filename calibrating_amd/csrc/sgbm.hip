@@ -1127,7 +1127,7 @@ static int launch_band(camd_sgbm* h, int sx, int sy, bool full, int mode, int ba
     }
     else if (!full && mode == 2 && h->persist_row > 0 && g.lanes == 16 && g.nr == 4) {
         // CAMD_OPT_RESIDENT: a fixed number of resident workgroups, runs of rows by ticket (sgbm_band.hpp)
-        const dim3 pgrid(h->persist_row * h->num_cus);
+        const dim3 pgrid(h->persist_row * (h->num_cus > 0 ? h->num_cus : 256));
         if (pad) hipLaunchKernelGGL((k_band_row_persist<16, 4, true>), pgrid, block, 0, st, a, g);
         else hipLaunchKernelGGL((k_band_row_persist<16, 4, false>), pgrid, block, 0, st, a, g);
     }
@@ -1598,7 +1598,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
             if (resident) {
                 const long long per_chunk = (long long)nstrips * ndblk * vbatch;
                 const int maxc = h->ga.H / 32 > 1 ? h->ga.H / 32 : 1;
-                nchunks = div_up(24LL * h->persist_cost * h->num_cus, per_chunk);
+                nchunks = div_up(24LL * h->persist_cost * (h->num_cus > 0 ? h->num_cus : 256), per_chunk);
                 nchunks = nchunks < 1 ? 1 : (nchunks > maxc ? maxc : nchunks);
             }
             const int rb = div_up(h->ga.H, nchunks);  // rows per chunk, in the longest range
@@ -1608,7 +1608,7 @@ int camd_sgbm_compute(camd_sgbm* h, const uint8_t* left, const uint8_t* right, s
             if (resident) {
                 uint32_t* tk = h->ticket + 3;  // (zeroed below, before the launches)
                 const int nx = nstrips, ny = nchunks * ndblk, nitems = nx * ny * vbatch;
-                const dim3 pgrid(h->persist_cost * h->num_cus);
+                const dim3 pgrid(h->persist_cost * (h->num_cus > 0 ? h->num_cus : 256));
 #define CAMD_COSTP(CNN, KK) hipLaunchKernelGGL((k_cost_persist<CNN, KK>), pgrid, block, lds, st, left, right, pitch, image_stride, \
                                                h->C, g, rb, nchunks, h->vol_elems, h->cr, tk, nx, ny, nitems)
                 if (g.cn == 1) { if (K == 5) CAMD_COSTP(1, 5); else CAMD_COSTP(1, 3); }
