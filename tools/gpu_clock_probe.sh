@@ -25,11 +25,11 @@ for PH in 1 2 4; do
   python /tmp/phase_loop.py $PH > /tmp/loop_$PH.log 2>&1 &
   PID=$!
   sleep 3.5
-  for i in 1 2 3 4 5 6; do rocm-smi --showclocks 2>/dev/null | grep -i "sclk" | head -1; sleep 0.25; done > /tmp/clk_$PH.txt
+  for i in 1 2 3 4 5 6; do rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|Power (W)" | head -2 | tr "\n" " "; echo; sleep 0.25; done > /tmp/clk_$PH.txt
   wait $PID
   echo "== $(grep phase /tmp/loop_$PH.log)" >> $O
   cat /tmp/clk_$PH.txt >> $O
 done
-echo "== idle" >> $O; rocm-smi --showclocks 2>/dev/null | grep -i "sclk" | head -1 >> $O
+echo "== idle" >> $O; rocm-smi --showclocks --showpower --showmaxpower 2>/dev/null | grep -i "sclk\|Power" | head -4 >> $O
 rocm-smi --showpower 2>/dev/null | grep -i "power" | head -3 >> $O
 cat $O
