@@ -61,6 +61,9 @@ static constexpr int COST_DL = 8;  // disparities per lane (the DL = 16 instanti
 #ifndef CAMD_COST_STAGE
 #define CAMD_COST_STAGE 1
 #endif
+#ifndef CAMD_COST_LDS_FLOOR_RGB
+#define CAMD_COST_LDS_FLOOR_RGB (41 * 1024)
+#endif
 // How C leaves the kernel.  A pixel's disparity vector (256 B at D = 128) is produced 16 bytes at a time by the waves of
 // one or two workgroups; stored straight from the registers, every wave's store instruction touches 64 different lines
 // with 16 bytes each and the L2 has to combine 8 or 16 such pieces per line -- for gray, whose arithmetic is a third of
@@ -160,7 +163,10 @@ static inline size_t cost_lds_bytes(int cn, int nwaves, int dl = COST_DL)
 {
     const int es = cn == 1 ? 4 : 12, dw = nwaves * dl;
     const int nr = 64 + dw - 1, nl = 64;
-    return (size_t)2 * (nr + nl) * es * 4 + (cost_tstore_shape(cn, nwaves, dl) ? (size_t)2 * 64 * (nwaves + 1) * 16 : 0);
+    const size_t need = (size_t)2 * (nr + nl) * es * 4 + (cost_tstore_shape(cn, nwaves, dl) ? (size_t)2 * 64 * (nwaves + 1) * 16 : 0);
+    // RGB at 8 waves: the kernel needs 64 VGPRs, so FOUR workgroups would fit a CU and fill every wave slot -- which leaves
+    // the other batch in flight (bench.py's second stream) no room beside it.  Asking for a third of the LDS keeps it at three.
+    return (cn == 3 && nwaves == 8 && need < CAMD_COST_LDS_FLOOR_RGB) ? (size_t)CAMD_COST_LDS_FLOOR_RGB : need;
 }
 
 // Only one dword of an entry's third quad is used; left alone the compiler narrows that read to ds_read_b32, whose 32
@@ -197,8 +203,12 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6, DW = NW * DL;
     const int tid = threadIdx.x;
     const int chunk = by % nchunks, dblk = by / nchunks;
-    const int vpair = bz, pair = vpair / cr.n, ridx = vpair % cr.n;  // volume index, image index, range
-    const int ybase = cr.start[ridx], nrows = cr.rows[ridx];
+    // (the division runs on the vector unit: say that its results are uniform, or everything derived from them -- image
+    // pointers, buffer descriptors, row addresses -- is treated as per-lane)
+    const int vpair = bz, pair = __builtin_amdgcn_readfirstlane(vpair / cr.n), ridx = __builtin_amdgcn_readfirstlane(vpair % cr.n);  // volume index, image index, range
+    // (indexing the by-value CostRanges with ridx goes through vector registers: tell the compiler the result is uniform, or
+    // every row address downstream is computed per lane in 64-bit vector arithmetic)
+    const int ybase = __builtin_amdgcn_readfirstlane(cr.start[ridx]), nrows = __builtin_amdgcn_readfirstlane(cr.rows[ridx]);
     if (chunk * rb >= nrows) return;  // (ranges shorter than the longest one: whole workgroup, before any barrier)
     // Two-stage build of a saturating volume (sgbm.hip): the wrapping kernel (SAT = false, rows in parallel chunks)
     // raises ovf[volume] when a value it writes exceeds ovf_thresh; this sequential kernel then only runs for the
@@ -264,22 +274,37 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
     // RGB pixels are fetched as ONE unaligned dword (R | G << 8 | B << 16 | next byte); the last column of a row is
     // fetched one byte early and shifted so that no load reaches past the row
     const bool st_last = CN == 3 && st_ccol == g.W - 1;
-    const uint8_t* st_ptr = (st_img == 1 ? imgL : imgR) + (size_t)st_ccol * CN - (st_last ? 1 : 0);
+    // byte offset of this lane's column inside an image row (the row itself is a scalar: see fetch_rows)
+    const uint32_t st_off = (uint32_t)(st_ccol * CN - (st_last ? 1 : 0));
     const uint32_t st_shift = st_last ? 8u : 0u;
     uint4* const st_dst = Ebuf + (st_img == 1 ? NRmax * EV : 0) + st_k * EV;  // + buffer * esz
 
     uint32_t rowA = 0, rowB = 0, rowC = 0;  // the three image rows of the column being staged (in flight)
     auto fetch_rows = [&](int y) {
         if (stager) {
-            const uint8_t* pm = st_ptr + (size_t)(y > 0 ? y - 1 : y) * pitch;
-            const uint8_t* p0 = st_ptr + (size_t)y * pitch;
-            const uint8_t* pp = st_ptr + (size_t)(y < H - 1 ? y + 1 : y) * pitch;
-            if (CN == 1) {
-                rowA = *pm; rowB = *p0; rowC = *pp;
+            // buffer loads: descriptor = the image ROW (a uniform 64-bit address the scalar unit computes; raw, byte-addressed),
+            // voffset = this lane's column -- no vector arithmetic per row (global loads from a per-lane 64-bit pointer
+            // cost three v_mad_u64_u32 + three 64-bit adds per staged row)
+            const size_t om = (size_t)(y > 0 ? y - 1 : y) * pitch, o0 = (size_t)y * pitch, op = (size_t)(y < H - 1 ? y + 1 : y) * pitch;
+            auto row_of_img = [&](const uint8_t* row) -> uint32_t {  // (row: uniform; the descriptor is scalar arithmetic)
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(row), 0, 0x7fffffff, 0x00020000);
+                if (CN == 1) return __builtin_amdgcn_raw_buffer_load_b8(rs, st_off, 0, 0);
+                return __builtin_amdgcn_raw_buffer_load_b32(rs, st_off, 0, 0);
+            };
+            auto rows_of = [&](const uint8_t* img) {
+                rowA = row_of_img(img + om);
+                rowB = row_of_img(img + o0);
+                rowC = row_of_img(img + op);
+            };
+            // (one wave of the four holds lanes of both images and runs both branches.  The empty asm statements keep the
+            // compiler from merging the branches into ONE load through a per-lane select of the descriptor, which it then
+            // has to serialise with a readfirstlane loop)
+            if (st_img == 1) {
+                rows_of(imgL);
+                asm volatile("; left image rows" ::: "memory");
             } else {
-                __builtin_memcpy(&rowA, pm, 4);
-                __builtin_memcpy(&rowB, p0, 4);
-                __builtin_memcpy(&rowC, pp, 4);
+                rows_of(imgR);
+                asm volatile("; right image rows" ::: "memory");
             }
         }
     };
@@ -387,7 +412,8 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
     const int xo = xo0 + lane - (K - 1);                                           // output column of this lane
     const bool writer = lane >= K - 1 && xo < W1 && d0 < g.Dp;
     const bool first_col = xo == 0;
-    uint16_t* const outp = Cout + (size_t)vpair * vol_stride + (size_t)(writer ? xo : 0) * g.Dp + d0;
+    uint16_t* const vol = Cout + (size_t)vpair * vol_stride;                 // (uniform)
+    const uint32_t out_off = (uint32_t)((writer ? xo : 0) * g.Dp + d0);     // element offset of this lane inside a row of C
 
     const int win_back = ((lane - K) & 63) << 2;
     const bool win_live = lane >= K;
@@ -402,11 +428,17 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
     const int tpx = w * (64 / NW) + lane / NW, tpc = lane % NW;
     const int txo = xo0 + tpx - (K - 1);
     const bool twriter = tpx >= K - 1 && txo < W1 && db + tpc * DL < g.Dp;
-    uint16_t* const toutp = Cout + (size_t)vpair * vol_stride + (size_t)(twriter ? txo : 0) * g.Dp + db + tpc * DL;
+    const uint32_t tout_off = (uint32_t)((twriter ? txo : 0) * g.Dp + db + tpc * DL);
+    // a 16-byte store into row `row` of C (uniform address) at element offset `off` of this lane: buffer store, the row in the
+    // descriptor (scalar arithmetic), the lane's part a 32-bit vector offset
+    auto store_c = [&](uint16_t* row, uint32_t off, u32x4_t v) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off * 2u, 0, 0);
+    };
     auto flush_row = [&](int r) {  // row step r's tile -> C (after the barrier that ended step r)
         if (twriter) {
             const uint4 v = Tbuf[((r & 1) * 64 + tpx) * TP + tpc];
-            *reinterpret_cast<uint4*>(toutp + (size_t)(y0 + r - (K - 1)) * W1 * g.Dp) = v;
+            store_c(vol + (size_t)(y0 + r - (K - 1)) * W1 * g.Dp, tout_off, u32x4_t{v.x, v.y, v.z, v.w});
         }
     };
     uint32_t acc[NP], ring[K][NP];
@@ -509,15 +541,15 @@ __device__ __forceinline__ void cost_body(const uint8_t* __restrict__ left, cons
                 if (tstore && r >= K - 1) Tbuf[((r & 1) * 64 + lane) * TP + w] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
                 if (r >= K - 1 && writer) {
                     const int y = y0 + r - (K - 1);
-                    uint4* o = reinterpret_cast<uint4*>(outp + (size_t)y * W1 * g.Dp);
+                    uint16_t* const orow = vol + (size_t)y * W1 * g.Dp;
 #pragma unroll
                     for (int q = 0; q < NP / 4; q++) {
                         if (tstore) {
                         } else if (CAMD_COST_NT)
                             __builtin_nontemporal_store(u32x4_t{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]},
-                                                        reinterpret_cast<u32x4_t*>(o) + q);
+                                                        reinterpret_cast<u32x4_t*>(orow + out_off) + q);
                         else
-                            o[q] = make_uint4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                            store_c(orow, out_off + 8 * q, u32x4_t{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
                         if (SAT) neg_min = pk_min_i16(pk_min_i16(neg_min, pk_min_i16(acc[4 * q], acc[4 * q + 1])),
                                                       pk_min_i16(acc[4 * q + 2], acc[4 * q + 3]));
                         if (!SAT && ovf_thresh >= 0)  // (uniform)
